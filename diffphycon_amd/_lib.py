@@ -1,0 +1,99 @@
+"""ctypes binding of libdpc.so (include/dpc.h).  There is NO fallback: if the HIP library is missing or fails
+to load, importing any compute entry raises — the product path never silently runs on something else."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdpc.so")
+_lib = None
+
+
+class StepCoef(C.Structure):
+    """dpc_step_coef (include/dpc.h)."""
+    _fields_ = [("sqrt_recip_ac", C.c_float), ("sqrt_recipm1_ac", C.c_float), ("mean_coef1", C.c_float),
+                ("mean_coef2", C.c_float), ("sigma", C.c_float), ("guide_scale", C.c_float), ("w_scale", C.c_float),
+                ("w_energy", C.c_float), ("mode", C.c_int32), ("clip_x_start", C.c_int32)]
+
+
+class Unet3DCfg(C.Structure):
+    """dpc_unet3d_cfg (include/dpc.h)."""
+    _fields_ = [("dim", C.c_int32), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 8), ("channels", C.c_int32),
+                ("out_dim", C.c_int32), ("attn_heads", C.c_int32), ("attn_dim_head", C.c_int32),
+                ("init_kernel", C.c_int32), ("groups", C.c_int32), ("micro_batch", C.c_int32)]
+
+
+_P, _I, _L, _Z, _D, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double, C.c_uint64
+
+_SIGNATURES = {
+    "dpc_version": (C.c_int, []),
+    "dpc_last_error": (C.c_char_p, []),
+    "dpc_unet3d_create": (C.c_int, [C.POINTER(Unet3DCfg), C.POINTER(_P)]),
+    "dpc_unet3d_destroy": (None, [_P]),
+    "dpc_unet3d_load": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(_L), _I, _P]),
+    "dpc_unet3d_set_tables": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
+    "dpc_unet3d_finalize": (C.c_int, [_P]),
+    "dpc_unet3d_workspace_bytes": (_Z, [_P, _I, _I, _I, _I]),
+    "dpc_unet3d_forward": (C.c_int, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
+    "dpc_unet3d_debug_taps": (C.c_int, [_P, _I]),
+    "dpc_unet3d_get_tap": (C.c_int, [_P, C.c_char_p, _P, _Z, _P]),
+    "dpc_ddpm_update_smoke": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(StepCoef), _I, _I, _I, _I, _I, _P]),
+    "dpc_philox_normal": (C.c_int, [_P, _I, _L, _U64, _L, _L, _P]),
+    "dpc_conv_workspace_bytes": (_Z, [_I, _I, _I]),
+    "dpc_conv3d_cl": (C.c_int, [_P, _P, _P, _P] + [_I] * 15 + [_P, _Z, _P]),
+    "dpc_convtranspose3d_144_cl": (C.c_int, [_P, _P, _P, _P] + [_I] * 6 + [_P, _Z, _P]),
+    "dpc_groupnorm_workspace_bytes": (_Z, [_I, _I]),
+    "dpc_groupnorm_silu_cl": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _Z, _P]),
+    "dpc_attention_core": (C.c_int, [_P, _P, _I, _I, _L, _L, _L, _L, _L, _P, _P, _P, _P]),
+    "dpc_linear_attention_workspace_bytes": (_Z, [_L, _I]),
+    "dpc_linear_attention_core": (C.c_int, [_P, _P, _I, _L, _I, _P, _Z, _P]),
+    "dpc_burgers_fd": (C.c_int, [_P, _P, _P, _I, _I, _I, _D, _D, _D, _P]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/dpc.h declares (checked by the CPU test-suite against the built library)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m diffphycon_amd.build` "
+                "(diffphycon_amd has no non-HIP fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libdpc error {rc}: {lib().dpc_last_error().decode()}")
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libdpc needs device tensors (the hot path has no CPU implementation)")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)

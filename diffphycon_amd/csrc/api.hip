@@ -1,0 +1,145 @@
+// extern "C" surface of libdpc (see include/dpc.h): error plumbing and the operator-level entry points.
+#include <memory>
+
+#include "common.h"
+
+namespace dpc {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+}  // namespace dpc
+
+using namespace dpc;
+
+extern "C" {
+
+int dpc_version(void) { return 100; }
+const char* dpc_last_error(void) { return g_err.c_str(); }
+
+int dpc_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z, const float* init,
+                          const float* rescaler, float* x_next, float* x0_out, const dpc_step_coef* coef, int B,
+                          int F, int C, int H, int W, dpc_stream_t stream) {
+    DPC_REQUIRE(x && eps_j && eps_w && init && rescaler && x_next && coef, "ddpm_update_smoke: null argument");
+    DPC_REQUIRE(B >= 0 && F >= 1 && H >= 1 && W >= 1, "ddpm_update_smoke: bad shape");
+    return launch_ddpm_update_smoke(x, eps_j, eps_w, z, init, rescaler, x_next, x0_out, *coef, B, F, C, H, W,
+                                    (hipStream_t)stream);
+}
+
+int dpc_philox_normal(float* out, int B, int64_t per_traj, uint64_t seed, int64_t traj0, int64_t draw,
+                      dpc_stream_t stream) {
+    DPC_REQUIRE(out && B >= 0 && per_traj >= 0, "philox_normal: bad argument");
+    return launch_philox_normal(out, B, per_traj, seed, traj0, draw, (hipStream_t)stream);
+}
+
+size_t dpc_conv_workspace_bytes(int Cin, int Cout, int ntaps) {
+    return (size_t)ntaps * igemm_kchunks(Cin) * igemm_npad(Cout) * 32 * sizeof(float) + 256;
+}
+
+int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, float* out_cl, int B, int F, int H, int W,
+                  int Cin, int Cout, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, void* ws,
+                  size_t ws_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(x_cl && w_ref && out_cl && ws, "conv3d_cl: null argument");
+    DPC_REQUIRE(sd == 1, "conv3d_cl: the frame axis is never strided (conv3d.py:159-163)");
+    const int ntaps = kd * kh * kw;
+    DPC_REQUIRE(ntaps >= 1 && ntaps <= 32, "conv3d_cl: 1..32 taps (the 7x7x7 stem has its own kernel)");
+    DPC_REQUIRE(ws_bytes >= dpc_conv_workspace_bytes(Cin, Cout, ntaps), "conv3d_cl: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = reinterpret_cast<float*>(align_up((size_t)ws, 256));
+    IgemmParams p{};
+    int off[32];
+    int t = 0;
+    for (int a = 0; a < kd; ++a)
+        for (int b = 0; b < kh; ++b)
+            for (int c = 0; c < kw; ++c, ++t) {
+                p.tdf[t] = (signed char)(a - pd);
+                p.tdh[t] = (signed char)(b - ph);
+                p.tdw[t] = (signed char)(c - pw);
+                off[t] = t;
+            }
+    p.N = Cout; p.Npad = igemm_npad(Cout); p.kchunks = igemm_kchunks(Cin); p.ntaps = ntaps;
+    int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s);
+    if (rc) return rc;
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    p.a0 = x_cl; p.a1 = nullptr; p.C0 = Cin; p.C1 = 0; p.wp = wp; p.bias = bias; p.resid = nullptr; p.out = out_cl;
+    p.BF = B * F; p.F = F; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.sh = sh; p.sw = sw;
+    p.out_mode = 0;
+    p.M = (long long)B * F * Ho * Wo;
+    return launch_igemm(p, s);
+}
+
+int dpc_convtranspose3d_144_cl(const float* x_cl, const float* w_ref, const float* bias, float* out_cl, int B, int F,
+                               int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(x_cl && w_ref && out_cl && ws, "convtranspose3d: null argument");
+    DPC_REQUIRE(ws_bytes >= 4 * dpc_conv_workspace_bytes(Cin, Cout, 4), "convtranspose3d: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per = align_up(dpc_conv_workspace_bytes(Cin, Cout, 4), 256);
+    const int dh_[2][2] = {{0, -1}, {1, 0}}, kh_[2][2] = {{1, 3}, {0, 2}};
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            float* wp = reinterpret_cast<float*>(align_up((size_t)ws, 256) + (size_t)(a * 2 + b) * per);
+            IgemmParams p{};
+            int off[32];
+            int t = 0;
+            for (int u = 0; u < 2; ++u)
+                for (int v = 0; v < 2; ++v, ++t) {
+                    p.tdf[t] = 0;
+                    p.tdh[t] = (signed char)dh_[a][u];
+                    p.tdw[t] = (signed char)dh_[b][v];
+                    off[t] = kh_[a][u] * 4 + kh_[b][v];
+                }
+            p.N = Cout; p.Npad = igemm_npad(Cout); p.kchunks = igemm_kchunks(Cin); p.ntaps = 4;
+            int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, 4, 16, (long long)Cout * 16, off, s);
+            if (rc) return rc;
+            p.a0 = x_cl; p.C0 = Cin; p.wp = wp; p.bias = bias; p.out = out_cl;
+            p.BF = B * F; p.F = F; p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W; p.sh = 1; p.sw = 1;
+            p.out_mode = 2; p.par_a = a; p.par_b = b;
+            p.M = (long long)B * F * H * W;
+            rc = launch_igemm(p, s);
+            if (rc) return rc;
+        }
+    return DPC_OK;
+}
+
+size_t dpc_groupnorm_workspace_bytes(int B, int C) { return gn_workspace_bytes(B, C) + 256; }
+
+int dpc_groupnorm_silu_cl(float* x_cl, const float* gamma, const float* beta, const float* scale_shift, int B,
+                          int64_t rows_per_sample, int C, int groups, void* ws, size_t ws_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(x_cl && gamma && beta && ws, "groupnorm_silu: null argument");
+    DPC_REQUIRE(ws_bytes >= dpc_groupnorm_workspace_bytes(B, C), "groupnorm_silu: workspace too small");
+    return launch_groupnorm_silu(x_cl, x_cl, nullptr, gamma, beta, scale_shift, B, rows_per_sample, C, groups,
+                                 reinterpret_cast<void*>(align_up((size_t)ws, 256)), (hipStream_t)stream);
+}
+
+int dpc_attention_core(const float* qkv, float* out, int heads, int L, int64_t n_seq, int64_t seq_inner,
+                       int64_t seq_outer_stride_rows, int64_t seq_inner_stride_rows, int64_t token_stride_rows,
+                       const float* rot_cos, const float* rot_sin, const float* bias, dpc_stream_t stream) {
+    DPC_REQUIRE(qkv && out && seq_inner >= 1, "attention_core: bad argument");
+    AttnParams p{};
+    p.qkv = qkv; p.out = out; p.heads = heads; p.L = L; p.n_seq = n_seq; p.seq_inner = seq_inner;
+    p.seq_outer_stride = seq_outer_stride_rows; p.seq_inner_stride = seq_inner_stride_rows;
+    p.token_stride = token_stride_rows; p.rot_cos = rot_cos; p.rot_sin = rot_sin; p.bias = bias;
+    return launch_attention(p, (hipStream_t)stream);
+}
+
+size_t dpc_linear_attention_workspace_bytes(int64_t images, int heads) {
+    return linattn_workspace_bytes(images, heads) + 256;
+}
+
+int dpc_linear_attention_core(const float* qkv, float* out, int heads, int64_t images, int N, void* ws, size_t ws_bytes,
+                              dpc_stream_t stream) {
+    DPC_REQUIRE(qkv && out && ws, "linear_attention_core: null argument");
+    DPC_REQUIRE(ws_bytes >= dpc_linear_attention_workspace_bytes(images, heads), "linear_attention_core: workspace too small");
+    return launch_linear_attention(qkv, out, heads, images, N, reinterpret_cast<void*>(align_up((size_t)ws, 256)),
+                                   (hipStream_t)stream);
+}
+
+int dpc_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, int num_t, double visc, double T,
+                   double dt, dpc_stream_t stream) {
+    DPC_REQUIRE(u0 && f && traj && N >= 0, "burgers_fd: bad argument");
+    return launch_burgers_fd(u0, f, traj, N, nx, num_t, visc, T, dt, (hipStream_t)stream);
+}
+
+}  // extern "C"

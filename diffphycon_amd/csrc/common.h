@@ -1,0 +1,128 @@
+// Internal helpers shared by the libdpc translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/dpc.h"
+
+namespace dpc {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define DPC_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return ::dpc::fail(DPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define DPC_LAUNCH_CHECK()                                                                               \
+    do {                                                                                                 \
+        hipError_t _e = hipGetLastError();                                                               \
+        if (_e != hipSuccess)                                                                            \
+            return ::dpc::fail(DPC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(_e) +     \
+                                                " at " + __FILE__ + ":" + std::to_string(__LINE__));     \
+    } while (0)
+
+#define DPC_REQUIRE(cond, msg)                                   \
+    do {                                                         \
+        if (!(cond)) return ::dpc::fail(DPC_ERR_ARG, (msg));     \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- implicit GEMM (igemm.hip)
+// out[m][n] = bias[n] + resid[m][n] + sum_{tap,c} A(m,tap,c) * W(tap,c,n)
+// A rows are output points (b,f,ho,wo) of a channels-last activation; see DESIGN.md.
+struct IgemmParams {
+    const float* a0;        // source 0, channels-last [B*F, Hi, Wi, C0]
+    const float* a1;        // source 1 (virtual concat along channels) or null
+    int C0, C1;
+    const float* wp;        // packed weights [ntaps][kchunks][Npad][32]
+    const float* bias;      // [N] or null
+    const float* resid;     // [M][N] or null (added after bias)
+    float* out;
+    const float* ln_stats;  // [rows][2] (mean, inv_std) or null: channel LayerNorm fused on the A operand
+    const float* ln_gamma;  // [K]
+    int BF, F;              // BF = B*F frames in total
+    int Hi, Wi, Ho, Wo;
+    int sh, sw;             // spatial stride of the input sampling
+    int ntaps;
+    int N, Npad, kchunks;
+    int out_mode;           // 0: [M][N]; 1: per-frame channels-first [BF][N][Ho*Wo]; 2: parity scatter into [BF][2Ho][2Wo][N]
+    int par_a, par_b;
+    signed char tdf[32], tdh[32], tdw[32];
+    long long M;
+};
+int igemm_npad(int N);
+int igemm_kchunks(int K);
+int launch_igemm(const IgemmParams& p, hipStream_t s);
+// generic weight re-pack: wp[tap][kc][n][kk] = w[n*stride_n + (kc*32+kk)*stride_c + tap_off[tap]]
+int launch_pack_weights(const float* w, float* wp, int N, int Npad, int K, int ntaps, long long stride_n,
+                        long long stride_c, const int* tap_off_host, hipStream_t s);
+
+// "gather" variant for the 7x7x7 stem on the reference-layout input [BF, C, H, W] (K = taps*C flattened)
+struct StemParams {
+    const float* x;         // [BF][C][H][W]
+    const float* wp;        // [kchunks][Npad][32]
+    const int* ktab;        // [kchunks*32] packed (df+64)<<24 | (dh+64)<<16 | (dw+64)<<8 | c ; -1 = padding
+    const float* bias;
+    float* out;             // channels-last [M][N]
+    int BF, F, C, H, W;
+    int Ctot, c_off;        // x is a channel slice [c_off, c_off+C) of a [BF][Ctot][H][W] tensor
+    int N, Npad, kchunks;
+    long long M;
+};
+int launch_stem(const StemParams& p, hipStream_t s);
+int launch_pack_stem(const float* w, float* wp, int* ktab, int N, int Npad, int C, int k, hipStream_t s);
+
+// ---------------------------------------------------------------- norms (norm.hip)
+int launch_ln_stats(const float* x, float* stats, long long rows, int C, hipStream_t s);
+size_t gn_workspace_bytes(int B, int C);
+// out = SiLU(GN(x)*(scale+1)+shift) (+ resid); out may alias x or resid (same-element in-place)
+int launch_groupnorm_silu(const float* x, float* out, const float* resid, const float* gamma, const float* beta,
+                          const float* scale_shift, int B, long long rows_per_sample, int C, int groups, void* ws,
+                          hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attn.hip)
+struct AttnParams {
+    const float* qkv;      // [rows][3*heads*32]
+    float* out;            // [rows][heads*32]
+    int heads, L;
+    long long n_seq, seq_inner, seq_outer_stride, seq_inner_stride, token_stride;   // in rows
+    const float* rot_cos;  // [L][32] or null
+    const float* rot_sin;
+    const float* bias;     // [heads][L][L] or null
+};
+int launch_attention(const AttnParams& p, hipStream_t s);
+size_t linattn_workspace_bytes(long long images, int heads);
+int launch_linear_attention(const float* qkv, float* out, int heads, long long images, int N, void* ws,
+                            hipStream_t s);
+
+// ---------------------------------------------------------------- small ops (small.hip)
+// out[b][n] = out_act( bias[n] + sum_k in_act(in[b][k]) * W[n][k] ),  act: 0 none, 1 SiLU, 2 GELU(erf)
+int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
+                        int in_act, int out_act, hipStream_t s);
+int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
+int launch_cl_to_cf(const float* x_cl, float* x_cf, int BF, int C, long long HW, int F, hipStream_t s);  // debug taps
+int launch_cf_to_cl(const float* x_cf, float* x_cl, int BF, int C, long long HW, hipStream_t s);
+
+// ---------------------------------------------------------------- sampler update (update.hip)
+int launch_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z,
+                             const float* init, const float* rescaler, float* x_next, float* x0_out,
+                             const dpc_step_coef& c, int B, int F, int C, int H, int W, hipStream_t s);
+int launch_philox_normal(float* out, int B, long long per_traj, uint64_t seed, long long traj0, long long draw,
+                         hipStream_t s);
+
+// ---------------------------------------------------------------- PDE evaluators
+int launch_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, int num_t, double visc, double T,
+                      double dt, hipStream_t s);
+
+}  // namespace dpc

@@ -1,0 +1,188 @@
+// Normalisation kernels on channels-last activations (HBM-bound streaming; float4 per lane).
+//   ln_stats       : per-row (mean, 1/sqrt(var+eps)) over C      -> consumed by igemm's A-operand prologue
+//   gn_partial     : per (sample, row-chunk, channel) sum / sum of squares, fp64 partials (deterministic)
+//   gn_apply_silu  : GroupNorm affine -> (scale+1, shift) -> SiLU, in place
+#include "common.h"
+
+namespace dpc {
+
+// ------------------------------------------------------------------ channel LayerNorm statistics
+// Reference: LayerNorm.forward (video_diffusion_pytorch_conv3d.py:171-174): biased variance over dim=1.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       long long rows, int C, int G /*lanes per row*/) {
+    const int lane = threadIdx.x & 63;
+    const int rows_per_wave = 64 / G;
+    const long long wave_id = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int sub = lane / G, gl = lane % G;
+    const int c4n = C >> 2;
+    for (long long r0 = wave_id * rows_per_wave; r0 < rows; r0 += nwaves * rows_per_wave) {
+        const long long r = r0 + sub;
+        const bool ok = r < rows;
+        float s = 0.f;
+        // first pass: mean
+        for (int c4 = gl; c4 < c4n; c4 += G) {
+            if (ok) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c4 * 4);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        for (int c4 = gl; c4 < c4n; c4 += G) {
+            if (ok) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c4 * 4);
+                const f32x4 d = v - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (ok && gl == 0) {
+            stats[2 * r] = mean;
+            stats[2 * r + 1] = 1.0f / sqrtf(q / (float)C + 1e-5f);
+        }
+    }
+}
+
+int launch_ln_stats(const float* x, float* stats, long long rows, int C, hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0, "ln_stats: C % 4");
+    int G = 1;
+    while (G < 64 && G < C / 4) G <<= 1;   // power-of-two lanes per row
+    const int rows_per_block = 4 * (64 / G);
+    const long long nb = (rows + rows_per_block - 1) / rows_per_block;
+    const int grid = (int)std::min<long long>(nb, 256 * 16);
+    if (grid == 0) return DPC_OK;
+    hipLaunchKernelGGL(ln_stats_kernel, dim3(grid), dim3(256), 0, s, x, stats, rows, C, G);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm + scale/shift + SiLU
+// Reference: Block.forward (…conv3d.py:196-204) with nn.GroupNorm(groups, C, eps=1e-5).
+constexpr int GN_MAX_CHUNKS = 128;
+
+static int gn_chunks(long long R, int C) {
+    const int tpr = C / 4;                 // threads per row
+    const int rows_per_pass = 256 / tpr;
+    long long n = R / ((long long)rows_per_pass * 32);
+    if (n < 1) n = 1;
+    if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+    return (int)n;
+}
+
+size_t gn_workspace_bytes(int B, int C) {
+    // fp64 partial sums [B][GN_MAX_CHUNKS][C][2]
+    return (size_t)B * GN_MAX_CHUNKS * C * 2 * sizeof(double);
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                         long long R, int C, int nchunk) {
+    __shared__ double red[256][8];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int tpr = C >> 2, rpp = 256 / tpr;
+    const int c4 = tid % tpr, rsub = tid / tpr;
+    const long long rpc = (R + nchunk - 1) / nchunk;
+    const long long r_begin = chunk * rpc, r_end = min(R, r_begin + rpc);
+    const float* xb = x + (long long)b * R * C;
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    for (long long r = r_begin + rsub; r < r_end; r += rpp) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
+        s += v;
+        q += v * v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[tid][i] = (double)s[i];
+        red[tid][4 + i] = (double)q[i];
+    }
+    __syncthreads();
+    if (tid < tpr) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < rpp; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += red[tid + k * tpr][i];
+        double* dst = part + (((long long)b * nchunk + chunk) * C + tid * 4) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[2 * i] = acc[i];
+            dst[2 * i + 1] = acc[4 + i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* out, const float* resid,
+                                                       const double* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ scale_shift, long long R, int C,
+                                                       int groups, int nchunk, int nblk) {
+    __shared__ float s_mean[1024], s_rstd[1024];   // per group (groups <= 1024)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups;
+    for (int g = tid; g < groups; g += 256) {
+        double s = 0, q = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* src = part + (((long long)b * nchunk + k) * C + g * cpg) * 2;
+            for (int c = 0; c < cpg; ++c) {
+                s += src[2 * c];
+                q += src[2 * c + 1];
+            }
+        }
+        const double n = (double)R * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const int tpr = C >> 2, rpp = 256 / tpr;
+    const int c4 = tid % tpr, rsub = tid / tpr;
+    float mu[4], ga[4], be[4], sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c4 * 4 + i, g = c / cpg;
+        mu[i] = s_mean[g];
+        ga[i] = s_rstd[g] * gamma[c];
+        be[i] = beta[c];
+        sc[i] = scale_shift ? scale_shift[(long long)b * 2 * C + c] + 1.0f : 1.0f;
+        sh[i] = scale_shift ? scale_shift[(long long)b * 2 * C + C + c] : 0.0f;
+    }
+    const float* xb = x + (long long)b * R * C;
+    float* ob = out + (long long)b * R * C;
+    const float* rb = resid ? resid + (long long)b * R * C : nullptr;
+    const long long rpb = (R + nblk - 1) / nblk;
+    const long long r_begin = blockIdx.x * rpb, r_end = min(R, r_begin + rpb);
+    for (long long r = r_begin + rsub; r < r_end; r += rpp) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y = (v[i] - mu[i]) * ga[i] + be[i];
+            if (scale_shift) y = y * sc[i] + sh[i];
+            v[i] = y / (1.0f + expf(-y));
+        }
+        if (rb) v += *reinterpret_cast<const f32x4*>(rb + r * C + c4 * 4);
+        *reinterpret_cast<f32x4*>(ob + r * C + c4 * 4) = v;
+    }
+}
+
+int launch_groupnorm_silu(const float* x, float* out, const float* resid, const float* gamma, const float* beta,
+                          const float* scale_shift, int B, long long R, int C, int groups, void* ws, hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0, "groupnorm: C/4 must divide 256");
+    DPC_REQUIRE(groups >= 1 && C % groups == 0 && groups <= 1024, "groupnorm: groups must divide C");
+    if (B == 0 || R == 0) return DPC_OK;
+    const int nchunk = gn_chunks(R, C);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, part, R, C, nchunk);
+    DPC_LAUNCH_CHECK();
+    const int rpp = 256 / (C / 4);
+    long long nblk = R / ((long long)rpp * 8);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, out, resid, part, gamma, beta,
+                       scale_shift, R, C, groups, nchunk, (int)nblk);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+}  // namespace dpc

@@ -1,0 +1,99 @@
+// Small host-latency-class ops of the denoiser: time-embedding MLP pieces and layout converters.
+#include "common.h"
+
+namespace dpc {
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return v / (1.0f + expf(-v));                               // SiLU
+    if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact GELU (nn.GELU default)
+    return v;
+}
+
+// out[b][n] = out_act(bias[n] + sum_k in_act(in[b][k]) W[n][k]); one wave per output element.
+// Reference: time_mlp (video_diffusion_pytorch_conv3d.py:404-409), ResnetBlock.mlp (:209-212).
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int K, int N, int in_act, int out_act) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)B * N) return;
+    const int b = (int)(wid / N), n = (int)(wid % N);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += act_apply(in[(long long)b * K + k], in_act) * W[(long long)n * K + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[(long long)b * N + n] = act_apply(s + (bias ? bias[n] : 0.f), out_act);
+}
+
+int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
+                        int in_act, int out_act, hipStream_t s) {
+    const long long total = (long long)B * N;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, in, W, bias, out, B, K,
+                       N, in_act, out_act);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// SinusoidalPosEmb (…conv3d.py:144-151): emb = t[:,None]*freqs[None,:]; cat(sin, cos)
+__global__ void sinusoidal_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
+                                  float* __restrict__ out, int B, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float e = __fmul_rn((float)t[b], freqs[j]);
+    out[(long long)b * 2 * half + j] = sinf(e);
+    out[(long long)b * 2 * half + half + j] = cosf(e);
+}
+
+int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s) {
+    const int n = B * half;
+    if (n == 0) return DPC_OK;
+    hipLaunchKernelGGL(sinusoidal_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, freqs, out, B, half);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// channels-last [BF][HW][C] -> channels-first [B][C][F][HW]   (debug taps / tests only)
+__global__ void cl_to_cf_kernel(const float* __restrict__ x, float* __restrict__ y, int BF, int C, long long HW,
+                                int F) {
+    const long long total = (long long)BF * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        long long r = i / HW;
+        const int f = (int)(r % F);
+        r /= F;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        y[i] = x[(((long long)b * F + f) * HW + hw) * C + c];
+    }
+}
+int launch_cl_to_cf(const float* x_cl, float* x_cf, int BF, int C, long long HW, int F, hipStream_t s) {
+    const long long total = (long long)BF * HW * C;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(cl_to_cf_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, s,
+                       x_cl, x_cf, BF, C, HW, F);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// per-frame channels-first [BF][C][HW] -> channels-last [BF][HW][C]
+__global__ void cf_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int BF, int C, long long HW) {
+    const long long total = (long long)BF * HW * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const long long hw = r % HW;
+        const long long bf = r / HW;
+        y[i] = x[(bf * C + c) * HW + hw];
+    }
+}
+int launch_cf_to_cl(const float* x_cf, float* x_cl, int BF, int C, long long HW, hipStream_t s) {
+    const long long total = (long long)BF * HW * C;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(cf_to_cl_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, s,
+                       x_cf, x_cl, BF, C, HW);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+}  // namespace dpc

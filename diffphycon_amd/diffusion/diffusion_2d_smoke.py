@@ -1,0 +1,313 @@
+"""Drop-in `GaussianDiffusion` for the smoke task: the reference's constructor and `.sample(...)` contract
+(/root/reference/diffusion/diffusion_2d_smoke.py:451-789) driving libdpc.
+
+Per step the hot path is: joint U-Net forward + prior U-Net forward (dpc_unet3d_forward) and ONE fused
+guidance + posterior update kernel (dpc_ddpm_update_smoke).  No autograd graph, no per-step host sync:
+every per-step scalar is taken from host-side fp64->fp32 tables built exactly as the reference builds its buffers.
+"""
+import ctypes as C
+import math
+from collections import namedtuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _lib
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def extract(a, t, x_shape):
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def linear_beta_schedule(timesteps):
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=torch.float64) / timesteps
+    alphas_cumprod = torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=torch.float64) / timesteps
+    v_start = torch.tensor(start / tau).sigmoid()
+    v_end = torch.tensor(end / tau).sigmoid()
+    alphas_cumprod = (-((t * (end - start) + start) / tau).sigmoid() + v_end) / (v_end - v_start)
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+class SmokeGuidance:
+    """The control objective of inference_2d_smoke.py:30-44 in closed form.
+
+    Calling it returns dJ/d(x*RESCALER) like the reference's `guidance_fn`; the sampler reads `.rescaler`
+    and `.w_energy` and evaluates the same expression inside the fused update kernel.
+    """
+
+    def __init__(self, rescaler, w_energy=0.0, w_init=0.0):
+        self.rescaler = torch.as_tensor(rescaler, dtype=torch.float32).reshape(-1)
+        self.w_energy = float(w_energy)
+        self.w_init = float(w_init)
+
+    def __call__(self, x, low=None, init=None, init_u=None):
+        b, f, c, h, w = x.shape
+        r = self.rescaler.to(x.device).reshape(1, 1, c, 1, 1)
+        g = torch.zeros_like(x)
+        g[:, -1, -1] += -1.0 / (h * w)
+        if self.w_energy != 0:
+            g[:, :, 3:5] += self.w_energy * 2.0 * (x * r)[:, :, 3:5] / (f * 2 * h * w)
+        return g
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, *, image_size, frames, timesteps=1000, sampling_timesteps=None, loss_type="l1",
+                 objective="pred_noise", beta_schedule="sigmoid", schedule_fn_kwargs=dict(), ddim_sampling_eta=0.,
+                 min_snr_loss_weight=False, min_snr_gamma=5, standard_fixed_ratio=0.01, coeff_ratio=0.1,
+                 eval_2ddpm=False, w_prob_exp=1.0, device=None):
+        super().__init__()
+        if eval_2ddpm:
+            self.model_joint, self.model_thetas = model
+            self.channels = self.model_joint.channels
+            self.self_condition = self.model_joint.self_condition
+        else:
+            self.model = model
+            self.channels = self.model.channels
+            self.self_condition = self.model.self_condition
+        self.is_w_model = self.channels == 2
+        self.image_size = image_size
+        self.frames = frames
+        self.objective = objective
+        self.standard_fixed_ratio = standard_fixed_ratio
+        self.coeff_ratio = coeff_ratio
+        self.eval_2ddpm = eval_2ddpm
+        self.w_prob_exp = w_prob_exp
+        assert objective in {"pred_noise"}, "the smoke sampler implements pred_noise (diffusion_2d_smoke.py:618)"
+
+        fn = {"linear": linear_beta_schedule, "cosine": cosine_beta_schedule, "sigmoid": sigmoid_beta_schedule}
+        if beta_schedule not in fn:
+            raise ValueError(f"unknown beta schedule {beta_schedule}")
+        betas = fn[beta_schedule](timesteps, **schedule_fn_kwargs)
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+
+        host = {}
+
+        def register_buffer(name, val):
+            v = val.to(torch.float32)
+            host[name] = v.clone()                      # host copy: per-step scalars without a device sync
+            self.register_buffer(name, v)
+
+        register_buffer("betas", betas)
+        register_buffer("alphas_cumprod", alphas_cumprod)
+        register_buffer("alphas_cumprod_prev", alphas_cumprod_prev)
+        register_buffer("sqrt_alphas_cumprod", torch.sqrt(alphas_cumprod))
+        register_buffer("sqrt_one_minus_alphas_cumprod", torch.sqrt(1. - alphas_cumprod))
+        register_buffer("log_one_minus_alphas_cumprod", torch.log(1. - alphas_cumprod))
+        register_buffer("sqrt_recip_alphas_cumprod", torch.sqrt(1. / alphas_cumprod))
+        register_buffer("sqrt_recipm1_alphas_cumprod", torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        register_buffer("posterior_variance", posterior_variance)
+        register_buffer("posterior_log_variance_clipped", torch.log(posterior_variance.clamp(min=1e-20)))
+        register_buffer("posterior_mean_coef1", betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        register_buffer("posterior_mean_coef2", (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+        snr = alphas_cumprod / (1 - alphas_cumprod)
+        maybe_clipped_snr = snr.clone()
+        if min_snr_loss_weight:
+            maybe_clipped_snr.clamp_(max=min_snr_gamma)
+        register_buffer("loss_weight", maybe_clipped_snr / snr)
+        self._host = host
+        self._host["sigma"] = (0.5 * host["posterior_log_variance_clipped"]).exp()          # (:685)
+        self._host["eta_alpha"] = self.coeff_ratio * host["betas"].clone().flip(0)           # (:632)
+        if device is not None:
+            self.to(device)
+        # counter-based noise: keyed (seed, global trajectory index, draw)
+        self.noise_seed = None          # None -> torch.initial_seed() at sample() time
+        self.traj_offset = 0            # global index of this rank's first trajectory
+        self._draw = 0
+
+    # ------------------------------------------------------------------ noise
+    def sample_noise(self, shape, device):
+        """Injection point like the reference's (:668); default: Philox stream per global trajectory."""
+        out = torch.empty(shape, device=device, dtype=torch.float32)
+        b = shape[0]
+        per = out.numel() // max(b, 1)
+        seed = torch.initial_seed() if self.noise_seed is None else self.noise_seed
+        _lib.check(_lib.lib().dpc_philox_normal(_lib.ptr(out), b, per, seed & (2 ** 64 - 1), self.traj_offset, self._draw,
+                                                _lib.stream()))
+        self._draw += 1
+        return out
+
+    # ------------------------------------------------------------------ one fused step
+    def _guidance(self, design_fn):
+        if not (hasattr(design_fn, "rescaler") and hasattr(design_fn, "w_energy")):
+            raise TypeError("design_fn must be a diffphycon_amd SmokeGuidance (closed-form objective of "
+                            "inference_2d_smoke.py:30-44); arbitrary autograd closures are not on the HIP path")
+        return design_fn.rescaler, design_fn.w_energy
+
+    def _update(self, x, eps_j, eps_w, z, init, rescaler_d, coef, x0_out=None):
+        B, Fr, Cc, H, W = x.shape
+        _lib.check(_lib.lib().dpc_ddpm_update_smoke(
+            _lib.ptr(x), _lib.ptr(eps_j), _lib.ptr(eps_w), _lib.ptr(z) if z is not None else None, _lib.ptr(init),
+            _lib.ptr(rescaler_d), _lib.ptr(x), _lib.ptr(x0_out) if x0_out is not None else None, C.byref(coef),
+            B, Fr, Cc, H, W, _lib.stream()))
+
+    def _coef_ddpm(self, t, design_guidance, w_energy):
+        h = self._host
+        c = _lib.StepCoef()
+        c.sqrt_recip_ac = h["sqrt_recip_alphas_cumprod"][t].item()
+        c.sqrt_recipm1_ac = h["sqrt_recipm1_alphas_cumprod"][t].item()
+        c.mean_coef1 = h["posterior_mean_coef1"][t].item()
+        c.mean_coef2 = h["posterior_mean_coef2"][t].item()
+        c.sigma = h["sigma"][t].item() if t > 0 else 0.0
+        if design_guidance == "standard":
+            c.guide_scale = self.standard_fixed_ratio
+        elif design_guidance == "standard-alpha":
+            c.guide_scale = h["eta_alpha"][t].item()
+        else:
+            raise ValueError(design_guidance)
+        c.w_scale = self.w_prob_exp - 1
+        c.w_energy = w_energy
+        c.mode, c.clip_x_start = 0, 0
+        return c
+
+    def _denoisers(self, x, t_b):
+        eps_j = self.model_joint(x, t_b)
+        eps_w = self.model_thetas(x[:, :, 3:5], t_b)          # channel view, read in place
+        return eps_j, eps_w
+
+    @torch.no_grad()
+    def p_sample(self, shape, x, t: int, x_self_cond=None, clip_denoised=True, design_fn=None,
+                 design_guidance="standard", low=None, init=None, init_u=None):
+        """One guided DDPM step (diffusion_2d_smoke.py:659-699) INCLUDING the in-paint of :720 (x is updated
+        in place and returned together with the clamped x0)."""
+        assert clip_denoised, "the reference always samples with clip_denoised=True"
+        rescaler, w_energy = self._guidance(design_fn)
+        dev = x.device
+        t_b = torch.full((x.shape[0],), t, device=dev, dtype=torch.long)
+        eps_j, eps_w = self._denoisers(x, t_b)
+        z = self.sample_noise(list(x.shape), dev) if t > 0 else None
+        x0 = torch.empty_like(x)
+        self._update(x, eps_j, eps_w, z, init, rescaler.to(dev), self._coef_ddpm(t, design_guidance, w_energy), x0)
+        return x, x0
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, design_fn=None, design_guidance="standard", return_all_timesteps=None, init=None,
+                      init_u=None, control=None, low=None, device=None):
+        b, f, c, h, w = shape
+        device = self.betas.device
+        assert init is not None
+        init = init.to(device=device, dtype=torch.float32).contiguous()
+        rescaler, w_energy = self._guidance(design_fn)
+        rescaler_d = rescaler.to(device)
+        x = self.sample_noise([b, f, c, h, w], device)
+        x[:, 0, 0] = init
+        for t in reversed(range(0, self.num_timesteps)):
+            t_b = torch.full((b,), t, device=device, dtype=torch.long)
+            eps_j, eps_w = self._denoisers(x, t_b)
+            z = self.sample_noise([b, f, c, h, w], device) if t > 0 else None
+            self._update(x, eps_j, eps_w, z, init, rescaler_d, self._coef_ddpm(t, design_guidance, w_energy))
+        return x
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, design_fn=None, design_guidance="standard", init=None, init_u=None, control=None,
+                    low=None, device=None):
+        batch, device, total, S, eta = shape[0], self.betas.device, self.num_timesteps, self.sampling_timesteps, \
+            self.ddim_sampling_eta
+        times = torch.linspace(-1, total - 1, steps=S + 1)
+        times = list(reversed(times.int().tolist()))
+        time_pairs = list(zip(times[:-1], times[1:]))
+        rescaler, w_energy = self._guidance(design_fn)
+        rescaler_d = rescaler.to(device)
+        init = init.to(device=device, dtype=torch.float32).contiguous()
+        img = self.sample_noise(list(shape), device)
+        img[:, 0, 0] = init
+        ac = self._host["alphas_cumprod"]
+        for time, time_next in time_pairs:
+            t_b = torch.full((batch,), time, device=device, dtype=torch.long)
+            eps_j, eps_w = self._denoisers(img, t_b)
+            c = self._coef_ddpm(time, design_guidance, w_energy)
+            c.clip_x_start = 1
+            if time_next < 0:
+                c.mode, c.sigma = 2, 0.0
+                self._update(img, eps_j, eps_w, None, init, rescaler_d, c)
+                continue
+            alpha, alpha_next = ac[time], ac[time_next]
+            sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()      # (:766)
+            cc = (1 - alpha_next - sigma ** 2).sqrt()                                              # (:767)
+            c.mode = 1
+            c.mean_coef1, c.mean_coef2, c.sigma = alpha_next.sqrt().item(), cc.item(), float(sigma)
+            z = self.sample_noise(list(shape), device)
+            self._update(img, eps_j, eps_w, z, init, rescaler_d, c)
+        return img
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, design_fn=None, design_guidance="standard", init=None, init_u=None, control=None,
+               low=None, device=None):
+        assert self.eval_2ddpm, "sampling uses the dual-model instance (inference_2d_smoke.py:111-125)"
+        image_size, channels, frames = self.image_size, self.channels, self.frames
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        assert batch_size == init.shape[0]
+        self._draw = 0
+        sample_size = (batch_size, frames, channels, image_size, image_size)
+        return sample_fn(sample_size, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low,
+                         device=device)
+
+
+class Trainer(object):
+    """Checkpoint READER only (training is out of scope): `Trainer(diffusion, dataset, dataset_path,
+    results_path=...).load(milestone)` as used by inference_2d_smoke.py:70-77,102-109; file format of
+    diffusion_2d_smoke.py:942-954 (`torch.save({'step','model','opt','ema','scaler'})`)."""
+
+    def __init__(self, diffusion_model, dataset=None, dataset_path=None, *, results_path="./results", amp=False,
+                 **unused):
+        from pathlib import Path
+        self.model = diffusion_model
+        self.channels = diffusion_model.channels
+        self.results_path = Path(results_path)
+        self.step = 0
+
+    @property
+    def device(self):
+        return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+    def load(self, milestone):
+        path = str(self.results_path / f"model-{milestone}.pt")
+        data = torch.load(path, map_location="cpu")
+        sd = {k: v for k, v in data["model"].items() if not k.endswith("rotary_emb.freqs")}
+        self.model.load_state_dict(sd)
+        self.step = data.get("step", 0)
+
+    def save(self, milestone):
+        self.results_path.mkdir(exist_ok=True, parents=True)
+        data = {"step": self.step, "model": self.model.state_dict(), "opt": None, "ema": None, "scaler": None}
+        torch.save(data, str(self.results_path / f"model-{milestone}.pt"))

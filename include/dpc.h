@@ -1,0 +1,167 @@
+/*
+ * libdpc — C-ABI boundary of the MI355X-native DiffPhyCon guided-sampling hot path.
+ *
+ * The reference (AI4Science-WestlakeU/diffphycon) has no FFI layer: the path sits behind plain
+ * Python call signatures.  The host side of this repo (diffphycon_amd/, Python) mirrors those
+ * signatures and binds the entry points below with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.  Each entry cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer named *_d / x / out / ws is a DEVICE pointer owned by the caller
+ *     (PyTorch-ROCm's allocator stays the single owner of HBM); the library never frees it;
+ *   - handles own only device copies of weights (re-packed for the kernels) and small tables;
+ *   - every entry returns 0 on success or a negative dpc_status; dpc_last_error() gives the
+ *     message (thread-local).  No exceptions, no exit() across the boundary;
+ *   - kernels are launched on the hipStream_t passed in (void* here so that C callers need
+ *     no HIP headers); no host synchronisation happens inside forward/update calls;
+ *   - all tensors fp32 contiguous unless stated; index types int64 where the reference uses
+ *     torch.long.
+ */
+#ifndef DPC_H
+#define DPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dpc_stream_t; /* hipStream_t */
+
+enum dpc_status {
+    DPC_OK = 0,
+    DPC_ERR_ARG = -1,        /* bad shape / null pointer / unsupported configuration */
+    DPC_ERR_STATE = -2,      /* handle not finalised, missing weight, workspace too small */
+    DPC_ERR_HIP = -3,        /* a HIP runtime call failed; message carries hipGetErrorString */
+    DPC_ERR_UNSUPPORTED = -4
+};
+
+int dpc_version(void);
+const char* dpc_last_error(void);
+
+/* ------------------------------------------------------------------ space-time U-Net denoiser
+ * Replaces model/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py
+ *   Unet3D_with_Conv3D.__init__ :357-471 (create/load), .forward :486-552 (forward).
+ */
+typedef struct dpc_unet3d_s* dpc_unet3d_t;
+
+typedef struct {
+    int32_t dim;            /* :359 */
+    int32_t n_mults;        /* len(dim_mults) :362 */
+    int32_t dim_mults[8];
+    int32_t channels;       /* :363 */
+    int32_t out_dim;        /* :361 (== channels when None) */
+    int32_t attn_heads;     /* :364 */
+    int32_t attn_dim_head;  /* :365  (only 32 is supported: one MFMA k-tile) */
+    int32_t init_kernel;    /* :368 */
+    int32_t groups;         /* :371 */
+    int32_t micro_batch;    /* trajectories per internal pass (0 = whole batch) */
+} dpc_unet3d_cfg;
+
+int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out);
+void dpc_unet3d_destroy(dpc_unet3d_t h);
+
+/* One call per state-dict entry, `name` as in the reference's state_dict() (e.g.
+ * "downs.0.0.block1.proj.weight"); `w_d` is a device pointer in the reference's layout and is
+ * re-packed into the kernels' layout on `stream`.  Unknown names -> DPC_ERR_ARG.
+ * (checkpoint reader side: diffusion/diffusion_2d_smoke.py:956-985) */
+int dpc_unet3d_load(dpc_unet3d_t h, const char* name, const float* w_d, const int64_t* shape, int ndim,
+                    dpc_stream_t stream);
+
+/* Small immutable tables computed once on the host in the reference's own arithmetic:
+ *   relpos_bias_d [heads, F, F]  = RelativePositionBias.forward(F)        (…conv3d.py:106-112)
+ *   rot_cos_d / rot_sin_d [F, attn_dim_head] interleaved-pair RoPE tables  (…conv3d.py:320-321, 380)
+ *   sin_freqs_d [dim/2]           = exp(arange(dim/2) * -log(1e4)/(dim/2-1)) (…conv3d.py:146-148)
+ */
+int dpc_unet3d_set_tables(dpc_unet3d_t h, int frames, const float* relpos_bias_d, const float* rot_cos_d,
+                          const float* rot_sin_d, const float* sin_freqs_d, dpc_stream_t stream);
+
+/* Verifies every parameter has been loaded. */
+int dpc_unet3d_finalize(dpc_unet3d_t h);
+
+size_t dpc_unet3d_workspace_bytes(dpc_unet3d_t h, int B, int F, int H, int W);
+
+/* x [B,F,C,H,W] fp32, t [B] int64 -> out [B,F,out_dim,H,W] fp32   (…conv3d.py:486-552).
+ * x may be a channel slice of a wider tensor [B,F,x_channels_total,H,W] starting at x_channel_offset (the
+ * prior model reads x[:, :, 3:5] of the joint state, diffusion_2d_smoke.py:612-613); pass 0,0 for a plain tensor. */
+int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int x_channel_offset, const int64_t* t,
+                       float* out, int B, int F, int H, int W, void* ws, size_t ws_bytes, dpc_stream_t stream);
+
+/* Debug/test hook: copy a named internal activation of the LAST micro-batch of the last forward,
+ * converted to the reference's channels-first layout [mb,C,F,H,W], into dst_d (caller-sized).
+ * Only active when enabled before the forward. Names as in oracle taps ("init_conv", "downs.0.0", …). */
+int dpc_unet3d_debug_taps(dpc_unet3d_t h, int enable);
+int dpc_unet3d_get_tap(dpc_unet3d_t h, const char* name, float* dst_d, size_t dst_floats, dpc_stream_t stream);
+
+/* ------------------------------------------------------------------ guided DDPM / DDIM update
+ * Replaces diffusion/diffusion_2d_smoke.py model_predictions :610-656 (after the two denoiser
+ * calls), p_mean_variance :659-666, p_sample :672-699, the in-paint of p_sample_loop :720 and
+ * the ddim_sample body :759-775, with the analytic gradient of inference_2d_smoke.py:30-44.
+ */
+typedef struct {
+    float sqrt_recip_ac;     /* extract(sqrt_recip_alphas_cumprod, t)   :578 */
+    float sqrt_recipm1_ac;   /* extract(sqrt_recipm1_alphas_cumprod, t) :579 */
+    float mean_coef1;        /* posterior_mean_coef1[t] :603  | DDIM: sqrt(alpha_next) :771 */
+    float mean_coef2;        /* posterior_mean_coef2[t] :604  | DDIM: c :767 */
+    float sigma;             /* exp(0.5*posterior_log_variance_clipped[t]) :685 (0 at t==0) | DDIM sigma :766 */
+    float guide_scale;       /* standard_fixed_ratio :630 or eta(t)=coeff_ratio*betas.flip(0)[t] :632-635 */
+    float w_scale;           /* (w_prob_exp - 1) :630 */
+    float w_energy;          /* inference_2d_smoke.py:41 */
+    int32_t mode;            /* 0 = DDPM p_sample, 1 = DDIM step, 2 = DDIM last step (return x0) */
+    int32_t clip_x_start;    /* DDIM: clip both x0 (:616,641) */
+} dpc_step_coef;
+
+/* x, eps_j, z, x_next: [B,F,C,H,W]; eps_w: [B,F,2,H,W]; init: [B,H,W]; rescaler: [C] (device).
+ * z may be NULL when sigma == 0.  x0_out may be NULL.  x_next may alias x.
+ * Guidance gradient channels follow the reference: objective on [b,F-1,C-1], energy and the
+ * prior-reweighting term on channels 3:5 (requires C >= 5). */
+int dpc_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z, const float* init,
+                          const float* rescaler, float* x_next, float* x0_out, const dpc_step_coef* coef, int B,
+                          int F, int C, int H, int W, dpc_stream_t stream);
+
+/* Counter-based N(0,1) noise keyed (seed, global trajectory index, draw index, element index):
+ * a trajectory's noise does not depend on how the batch is sharded over GPUs.
+ * out [B, per_traj] ; traj0 = global index of the first local trajectory. */
+int dpc_philox_normal(float* out, int B, int64_t per_traj, uint64_t seed, int64_t traj0, int64_t draw,
+                      dpc_stream_t stream);
+
+/* ------------------------------------------------------------------ operator-level entry points
+ * (used by the parity tests; the U-Net forward composes exactly these kernels)
+ * Activations are channels-last [B,F,H,W,C] ("rows" = B*F*H*W points).
+ */
+/* Conv3d with reference-layout weight [Cout,Cin,kd,kh,kw] (nn.Conv3d, …conv3d.py:192,163,216,392,470) */
+int dpc_conv3d_cl(const float* x_cl, const float* w_ref_d, const float* bias_d, float* out_cl, int B, int F, int H,
+                  int W, int Cin, int Cout, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw,
+                  void* ws, size_t ws_bytes, dpc_stream_t stream);
+/* ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1), weight [Cin,Cout,1,4,4] (…conv3d.py:159-160) */
+int dpc_convtranspose3d_144_cl(const float* x_cl, const float* w_ref_d, const float* bias_d, float* out_cl, int B,
+                               int F, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                               dpc_stream_t stream);
+size_t dpc_conv_workspace_bytes(int Cin, int Cout, int ntaps);
+/* GroupNorm(groups, eps 1e-5, affine) -> *(scale+1)+shift (optional, [B,2C] as chunked in :223-225) -> SiLU,
+ * in place on x_cl (…conv3d.py:193-204) */
+int dpc_groupnorm_silu_cl(float* x_cl, const float* gamma_d, const float* beta_d, const float* scale_shift_d, int B,
+                          int64_t rows_per_sample, int C, int groups, void* ws, size_t ws_bytes, dpc_stream_t stream);
+size_t dpc_groupnorm_workspace_bytes(int B, int C);
+size_t dpc_linear_attention_workspace_bytes(int64_t images, int heads);
+/* Attention core on a packed qkv tensor [rows, 3*heads*32]: sequences of L tokens, token stride and
+ * sequence addressing given in rows; optional rotary tables [L,32] and bias [heads,L,L]
+ * (…conv3d.py:311-351).  out [rows, heads*32]. */
+int dpc_attention_core(const float* qkv, float* out, int heads, int L, int64_t n_seq, int64_t seq_inner,
+                       int64_t seq_outer_stride_rows, int64_t seq_inner_stride_rows, int64_t token_stride_rows,
+                       const float* rot_cos_d, const float* rot_sin_d, const float* bias_d, dpc_stream_t stream);
+/* Spatial linear attention core (…conv3d.py:246-255) on qkv [images*N, 3*heads*32] -> out [images*N, heads*32] */
+int dpc_linear_attention_core(const float* qkv, float* out, int heads, int64_t images, int N, void* ws,
+                              size_t ws_bytes, dpc_stream_t stream);
+
+/* ------------------------------------------------------------------ Burgers finite-difference solver
+ * Replaces dataset/apps/generate_burgers.py:207-299 burgers_numeric_solve_free (fp32, explicit Euler).
+ * u0 [N,nx], f [N,num_t,nx] -> traj [N,num_t+1,nx]. */
+int dpc_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, int num_t, double visc, double T,
+                   double dt, dpc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPC_H */

@@ -1,0 +1,210 @@
+"""GPU parity of the operator-level C-ABI entry points (include/dpc.h) against the CPU oracle / plain torch fp32.
+
+Run on the MI355X box:  python -m pytest tests -m gpu
+Tolerances are stated per test (per-block fp32 rel 1e-5 / abs 1e-6 scaled by the reduction length).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from diffphycon_amd import _lib
+    return _lib
+
+
+def to_cl(x):      # [B,C,F,H,W] -> [B,F,H,W,C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_cf(x):      # [B,F,H,W,C] -> [B,C,F,H,W]
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def relerr(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+CONV_CASES = [
+    # B, F, H, W, Cin, Cout, k, stride, pad
+    (2, 4, 16, 16, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 3, 8, 12, 16, 24, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 5, 16, 16, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 4, 8, 8, 256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 4, 16, 16, 64, 64, (1, 4, 4), (1, 2, 2), (0, 1, 1)),
+    (2, 3, 8, 8, 128, 6, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (1, 2, 6, 10, 40, 72, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_cl(case, dev, L):
+    B, Fr, H, W, Ci, Co, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = torch.randn(B, Ci, Fr, H, W, generator=g)
+    w = torch.randn(Co, Ci, *k, generator=g) / (Ci * k[0] * k[1] * k[2]) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv3d(x.double(), w.double(), b.double(), stride=s, padding=p).float()
+    xd, wd, bd = to_cl(x).to(dev), w.to(dev).contiguous(), b.to(dev)
+    out = torch.empty(to_cl(ref).shape, device=dev)
+    nb = L.lib().dpc_conv_workspace_bytes(Ci, Co, k[0] * k[1] * k[2])
+    ws = L.workspace(nb, dev)
+    L.check(L.lib().dpc_conv3d_cl(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), B, Fr, H, W, Ci, Co, *k, *s, *p,
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    got = to_cf(out.cpu())
+    # fp32 MFMA accumulation over K = Cin*taps terms vs an fp64 reference
+    assert relerr(got, ref) < 2e-6 * (Ci * k[0] * k[1] * k[2]) ** 0.5 + 1e-6, relerr(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 8, 8, 16, 16), (1, 3, 16, 16, 128, 128), (1, 2, 4, 6, 64, 32)])
+def test_convtranspose3d_144(shape, dev, L):
+    B, Fr, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Ci, Fr, H, W, generator=g)
+    w = torch.randn(Ci, Co, 1, 4, 4, generator=g) / (Ci * 4) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv_transpose3d(x.double(), w.double(), b.double(), stride=(1, 2, 2), padding=(0, 1, 1)).float()
+    xd, wd, bd = to_cl(x).to(dev), w.to(dev).contiguous(), b.to(dev)
+    out = torch.full(to_cl(ref).shape, float("nan"), device=dev)
+    nb = 4 * L.lib().dpc_conv_workspace_bytes(Ci, Co, 4)
+    ws = L.workspace(nb, dev)
+    L.check(L.lib().dpc_convtranspose3d_144_cl(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), B, Fr, H, W, Ci, Co,
+                                               C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    got = to_cf(out.cpu())
+    assert torch.isfinite(got).all()
+    assert relerr(got, ref) < 1e-5, relerr(got, ref)
+
+
+@pytest.mark.parametrize("B,R,Cc,G,ss", [(2, 1024, 8, 8, True), (2, 4 * 16 * 16, 16, 8, False), (1, 32 * 64 * 64, 64, 8, True),
+                                         (3, 2000, 256, 8, True), (2, 333, 64, 1, False)])
+def test_groupnorm_silu(B, R, Cc, G, ss, dev, L):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, R, Cc, generator=g) * 2 + 0.7
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    scsh = torch.randn(B, 2 * Cc, generator=g) * 0.3 if ss else None
+    xc = x.permute(0, 2, 1).double()                                   # [B,C,R]
+    ref = F.group_norm(xc, G, gamma.double(), beta.double(), eps=1e-5)
+    if ss:
+        sc, sh = scsh.double().chunk(2, dim=1)
+        ref = ref * (sc[:, :, None] + 1) + sh[:, :, None]
+    ref = F.silu(ref).permute(0, 2, 1).float()
+    xd = x.to(dev).contiguous()
+    ws = L.workspace(L.lib().dpc_groupnorm_workspace_bytes(B, Cc), dev)
+    L.check(L.lib().dpc_groupnorm_silu_cl(L.ptr(xd), L.ptr(gamma.to(dev)), L.ptr(beta.to(dev)),
+                                          L.ptr(scsh.to(dev)) if ss else None, B, R, Cc, G,
+                                          C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    got = xd.cpu()
+    assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5), (got - ref).abs().max()
+
+
+def _attn_ref(qkv, heads, rot, bias):
+    """qkv [..., n, 3*heads*32] -> [..., n, heads*32], float64 reference of Attention.forward (…conv3d.py:311-351)."""
+    from oracle import unet3d as O
+    q, k, v = [z.reshape(*z.shape[:-1], heads, 32).transpose(-2, -3) for z in qkv.double().chunk(3, dim=-1)]
+    q = q * 32 ** -0.5
+    if rot:
+        q, k = O.rotary(q.float()).double(), O.rotary(k.float()).double()
+    sim = torch.einsum("...hid,...hjd->...hij", q, k)
+    if bias is not None:
+        sim = sim + bias.double()
+    attn = sim.softmax(dim=-1)
+    out = torch.einsum("...hij,...hjd->...hid", attn, v)
+    return out.transpose(-2, -3).reshape(*qkv.shape[:-1], heads * 32).float()
+
+
+@pytest.mark.parametrize("B,Fr,HW", [(2, 4, 16), (1, 32, 64), (2, 20, 12), (1, 64, 8), (1, 33, 5)])
+def test_attention_core_temporal(B, Fr, HW, dev, L):
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import _rotary_tables
+    heads = 4
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, Fr, HW, 3 * heads * 32, generator=g)           # rows ordered (b, f, pixel)
+    bias = torch.randn(heads, Fr, Fr, generator=g)
+    ref = _attn_ref(qkv.permute(0, 2, 1, 3), heads, True, bias).permute(0, 2, 1, 3).contiguous()
+    cos, sin = _rotary_tables(Fr, 32)
+    out = torch.empty(B, Fr, HW, heads * 32, device=dev)
+    L.check(L.lib().dpc_attention_core(L.ptr(qkv.to(dev)), L.ptr(out), heads, Fr, B * HW, HW, Fr * HW, 1, HW,
+                                       L.ptr(cos.to(dev)), L.ptr(sin.to(dev)), L.ptr(bias.to(dev)), L.stream()))
+    got = out.cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("BF,N", [(3, 64), (2, 256), (2, 16), (1, 100)])
+def test_attention_core_spatial(BF, N, dev, L):
+    heads = 4
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(BF, N, 3 * heads * 32, generator=g) * 1.5
+    ref = _attn_ref(qkv, heads, False, None)
+    out = torch.empty(BF, N, heads * 32, device=dev)
+    L.check(L.lib().dpc_attention_core(L.ptr(qkv.to(dev)), L.ptr(out), heads, N, BF, 1, N, 0, 1, None, None, None,
+                                       L.stream()))
+    got = out.cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("imgs,N", [(3, 256), (2, 64), (1, 4096), (2, 50)])
+def test_linear_attention_core(imgs, N, dev, L):
+    heads = 4
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(imgs, N, 3 * heads * 32, generator=g) * 1.5
+    q, k, v = [z.reshape(imgs, N, heads, 32).permute(0, 2, 3, 1).double() for z in qkv.chunk(3, dim=-1)]   # b h d n
+    q = q.softmax(dim=-2) * 32 ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(imgs, N, heads * 32).float()
+    out = torch.empty(imgs, N, heads * 32, device=dev)
+    ws = L.workspace(L.lib().dpc_linear_attention_workspace_bytes(imgs, heads), dev)
+    L.check(L.lib().dpc_linear_attention_core(L.ptr(qkv.to(dev)), L.ptr(out), heads, imgs, N,
+                                              C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    got = out.cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6), (got - ref).abs().max()
+
+
+def test_burgers_fd_bit_exact(dev, L):
+    from oracle import burgers as OB
+    g = load_golden("burgers_fd")
+    for u0, f, visc, T, dt, nt, key in ((g["u0"], g["f"], 0.01, 1.0, 1e-4, 10, "traj"),
+                                        (g["u0b"], g["fb"], 0.02, 0.5, 5e-4, 4, "trajb")):
+        N, nx = u0.shape
+        out = torch.empty(N, nt + 1, nx, device=dev)
+        L.check(L.lib().dpc_burgers_fd(L.ptr(torch.from_numpy(u0).to(dev)), L.ptr(torch.from_numpy(f).to(dev)),
+                                       L.ptr(out), N, nx, nt, visc, T, dt, L.stream()))
+        got = out.cpu().numpy()
+        # integer index schedule + fp32 stencil: bit-exact against the oracle AND against the reference fixture
+        assert np.array_equal(got, OB.burgers_numeric_solve_free(u0, f, visc, T, dt, nt))
+        assert np.array_equal(got, g[key])
+    # a batch that does not fill the last workgroup, synthetic inputs
+    u0, f = OB.synthetic_inputs(50, 128, 10, seed=3)
+    out = torch.empty(50, 11, 128, device=dev)
+    L.check(L.lib().dpc_burgers_fd(L.ptr(torch.from_numpy(u0).to(dev)), L.ptr(torch.from_numpy(f).to(dev)), L.ptr(out),
+                                   50, 128, 10, 0.01, 1.0, 1e-4, L.stream()))
+    assert np.array_equal(out.cpu().numpy(), OB.burgers_numeric_solve_free(u0, f, 0.01, 1.0, 1e-4, 10))
+
+
+def test_philox_normal_sharding_invariance(dev, L):
+    per = 4 * 6 * 16 * 16 + 3
+    full = torch.empty(8, per, device=dev)
+    L.check(L.lib().dpc_philox_normal(L.ptr(full), 8, per, 1234, 0, 5, L.stream()))
+    part = torch.empty(3, per, device=dev)
+    L.check(L.lib().dpc_philox_normal(L.ptr(part), 3, per, 1234, 4, 5, L.stream()))
+    assert torch.equal(full[4:7], part)                       # trajectory 4..6 drawn identically on "another rank"
+    other = torch.empty(8, per, device=dev)
+    L.check(L.lib().dpc_philox_normal(L.ptr(other), 8, per, 1234, 0, 6, L.stream()))
+    assert not torch.equal(full, other)
+    big = torch.empty(64, 65536, device=dev)
+    L.check(L.lib().dpc_philox_normal(L.ptr(big), 64, 65536, 7, 0, 0, L.stream()))
+    assert abs(big.mean().item()) < 2e-3 and abs(big.std().item() - 1) < 2e-3
+    assert abs((big ** 4).mean().item() - 3) < 0.05
