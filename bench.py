@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: guided trajectories/sec, 2-D smoke 64x64x32 @ 1000 DDPM steps (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is ONE guided DDPM step of the whole local batch (config S64: 64 trajectories per GPU):
+joint U-Net forward + prior U-Net forward + fused guidance/posterior update — i.e. 1/1000 of the sampling of
+each trajectory.  trajectories/s = (N * 64) / (1000 * seconds_per_step).  Inputs and state are resident in
+HBM before the timed region; weights are seeded random initialisations of the reference architecture
+(no checkpoints exist offline) and data is synthetic.
+
+The JSON line also carries
+  roofline     : achieved fp32 TFLOP/s of the dominant kernel class (the implicit-GEMM conv kernel), from HIP
+                 events recorded on the launch stream inside the timed region, against the 157.3 TF fp32 MFMA peak;
+  cpu_baseline : the CPU oracle (torch fp32, all host cores) executing the same step at B=1, timed once.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3         # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+STEPS_PER_TRAJECTORY = 1000
+LOCAL_BATCH = 64
+FRAMES, SIZE = 32, 64
+
+
+def synthetic_init(batch, traj0, size=SIZE):
+    """zeros with a 5x5 block of ones at rows 10..25 / cols 12..52, init = density / 2."""
+    init = torch.zeros(batch, size, size)
+    g = torch.Generator().manual_seed(0)
+    pos = torch.stack((torch.randint(10, 26, (4096,), generator=g), torch.randint(12, 53, (4096,), generator=g)), 1)
+    for b in range(batch):
+        r, c = pos[(traj0 + b) % 4096].tolist()
+        init[b, r:r + 5, c:c + 5] = 0.5
+    return init
+
+
+def build_models(device, micro_batch):
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion
+    torch.manual_seed(0)
+    mj = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, micro_batch=micro_batch)
+    mw = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=2, micro_batch=micro_batch)
+    sd_cpu = (mj.state_dict(), mw.state_dict())
+    sd_cpu = tuple({k: v.clone() for k, v in sd.items()} for sd in sd_cpu)
+    gd = GaussianDiffusion([mj.to(device), mw.to(device)], image_size=SIZE, frames=FRAMES, timesteps=1000,
+                           sampling_timesteps=1000, loss_type="l2", objective="pred_noise", standard_fixed_ratio=1e5,
+                           coeff_ratio=0.0, eval_2ddpm=True, w_prob_exp=0.97, device=device)
+    return gd, sd_cpu
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows
+    256 logical CPUs but a 16-CPU quota; oversubscribing oneDNN by 16x stalls for tens of minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(sd_cpu, init1):
+    """One guided DDPM step, B=1, on the CPU oracle (the reference's algorithm restated in torch fp32)."""
+    from oracle import unet3d as O
+    from oracle import sampler_smoke as S
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    cj = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
+    cw = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=2)
+    sched = S.make_schedule(1000, "sigmoid")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, FRAMES, 6, SIZE, SIZE, generator=g)
+    z = torch.randn(1, FRAMES, 6, SIZE, SIZE, generator=g)
+    x[:, 0, 0] = init1
+    t = torch.full((1,), 999, dtype=torch.long)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ej = O.unet3d_forward(sd_cpu[0], cj, x, t)
+        ew = O.unet3d_forward(sd_cpu[1], cw, x[:, :, 3:5], t)
+        S.p_sample_step(sched, x, 999, ej, ew, z, init1, S.rescaler_tensor())
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (STEPS_PER_TRAJECTORY * dt), "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"1 guided DDPM step (joint+prior U-Net forward + update) at B=1, 64x64x32, torch fp32 on {cores} "
+                      f"threads: {dt:.2f} s/step, extrapolated x1000 steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=LOCAL_BATCH, help="trajectories per GPU (S64 = 64)")
+    ap.add_argument("--micro-batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+
+    from diffphycon_amd import _lib
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
+    gd, sd_cpu = build_models(device, args.micro_batch)
+    guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
+    B = args.batch
+    gd.noise_seed, gd.traj_offset = 0, rank * B            # batch-sharded: rank r owns trajectories [r*B, (r+1)*B)
+    init_cpu = synthetic_init(B, rank * B)
+    init = init_cpu.to(device)
+    x = gd.sample_noise([B, FRAMES, 6, SIZE, SIZE], device)
+    x[:, 0, 0] = init
+
+    def step(t):
+        gd.p_sample(None, x, t, design_fn=guide, design_guidance="standard", init=init)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_cur = 999
+    log("models built, starting warmup")
+    for _ in range(args.warmup):
+        step(t_cur)
+        t_cur -= 1
+        sync()
+        log("warmup step done")
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(t_cur)
+        t_cur -= 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    log(f"timed steps done: {elapsed:.3f}s")
+    prof = _lib.profile_end()
+    log("profile read")
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(x).all(), "non-finite state after the timed steps"
+
+    if rank == 0:
+        sec_per_step = elapsed / args.steps
+        value = world * B / (STEPS_PER_TRAJECTORY * sec_per_step)
+        # dominant kernel class by total time
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        name, d = dom
+        if d["flops"] > 0:
+            achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
+        else:
+            achieved = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": None}
+        roof["kernel"] = name
+        roof["launches"] = d["launches"]
+        roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
+        gpu_ms = sum(v["total_ms"] for v in prof.values())
+        roof["breakdown_ms_per_step"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())}
+        roof["kernel_time_fraction_of_step"] = gpu_ms / (elapsed * 1e3)
+        unit_gflop = 1794.5        # algorithmic GFLOP per trajectory-step (both U-Nets)
+        roof["step_flops_fraction_of_fp32_peak"] = (B * unit_gflop / 1e3 / sec_per_step) / PEAK_FP32_MFMA_TFLOPS
+        out = {
+            "metric": "guided trajectories/sec, 2D smoke 64x64x32 @1000 DDPM steps",
+            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames, 1000-step guided DDPM, "
+                                   f"batch={B} per GPU; one step = joint+prior Unet3D(dim 64, mults 1-2-4) forward + "
+                                   "fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",
+                       "global_batch": world * B, "micro_batch": args.micro_batch, "parallelism": f"batch-shard x{world}"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, init_cpu[:1])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,11 +24,32 @@ class Unet3DCfg(C.Structure):
                 ("init_kernel", C.c_int32), ("groups", C.c_int32), ("micro_batch", C.c_int32)]
 
 
+class ProfileRow(C.Structure):
+    """dpc_profile_row (include/dpc.h)."""
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+def profile_begin():
+    check(lib().dpc_profile_begin())
+
+
+def profile_end():
+    """-> {class name: dict(launches, total_ms, flops, bytes)} for the launches since profile_begin()."""
+    rows = (ProfileRow * 32)()
+    n = C.c_int(0)
+    check(lib().dpc_profile_end(C.cast(rows, C.c_void_p), 32, C.byref(n)))
+    return {rows[i].name.decode(): dict(launches=rows[i].launches, total_ms=rows[i].total_ms, flops=rows[i].flops,
+                                        bytes=rows[i].bytes) for i in range(n.value)}
+
+
 _P, _I, _L, _Z, _D, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double, C.c_uint64
 
 _SIGNATURES = {
     "dpc_version": (C.c_int, []),
     "dpc_last_error": (C.c_char_p, []),
+    "dpc_profile_begin": (C.c_int, []),
+    "dpc_profile_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dpc_unet3d_create": (C.c_int, [C.POINTER(Unet3DCfg), C.POINTER(_P)]),
     "dpc_unet3d_destroy": (None, [_P]),
     "dpc_unet3d_load": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(_L), _I, _P]),

@@ -150,6 +150,8 @@ int launch_attention(const AttnParams& p, hipStream_t s) {
     if (total == 0) return DPC_OK;
     const long long grid = (total + 3) / 4;
     DPC_REQUIRE(grid < (1ll << 31), "attention: grid too large");
+    const double rows = (double)p.n_seq * p.L;
+    ProfScope prof(PROF_ATTN, 4.0 * rows * p.L * 32 * p.heads, 4.0 * rows * 4 * p.heads * 32, s);
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, total, qtiles);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
@@ -269,6 +271,8 @@ int launch_linear_attention(const float* qkv, float* out, int heads, long long i
     if (images == 0) return DPC_OK;
     float* ctx = reinterpret_cast<float*>(ws);
     DPC_REQUIRE(images * heads < (1ll << 31), "linear attention: grid too large");
+    const double rows_ = (double)images * N;
+    ProfScope prof(PROF_LINATTN, 4.0 * rows_ * 32 * 32 * heads, 4.0 * rows_ * heads * 32 * 6, s);
     hipLaunchKernelGGL(linattn_ctx_kernel, dim3((unsigned)(images * heads)), dim3(256), 0, s, qkv, ctx, heads, N);
     DPC_LAUNCH_CHECK();
     const int tiles = (N + 31) / 32;

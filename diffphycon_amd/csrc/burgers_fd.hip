@@ -91,6 +91,7 @@ int launch_burgers_fd(const float* u0, const float* f, float* traj, int N, int n
     k.d_r = k.d_l;
     k.dt = (float)dt;
     const int grid = (N + 3) / 4;
+    ProfScope prof(PROF_BURGERS, 0, 4.0 * (double)N * nx * (2 * num_t + 2), s);
     if (nx <= 64) hipLaunchKernelGGL(burgers_fd_kernel<1>, dim3(grid), dim3(256), 0, s, u0, f, traj, N, nx, num_t, k);
     else if (nx <= 128) hipLaunchKernelGGL(burgers_fd_kernel<2>, dim3(grid), dim3(256), 0, s, u0, f, traj, N, nx, num_t, k);
     else hipLaunchKernelGGL(burgers_fd_kernel<4>, dim3(grid), dim3(256), 0, s, u0, f, traj, N, nx, num_t, k);

@@ -35,6 +35,18 @@ int fail(int code, const std::string& msg);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------- opt-in event timing (profile.hip)
+enum ProfClass {
+    PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
+    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_NCLASS
+};
+struct ProfScope {
+    ProfScope(int cls, double flops, double bytes, hipStream_t s);
+    ~ProfScope();
+    long long idx_;
+    hipStream_t s_;
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

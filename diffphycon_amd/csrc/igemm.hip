@@ -206,6 +206,10 @@ int launch_igemm(const IgemmParams& p, hipStream_t s) {
     DPC_REQUIRE(p.kchunks == igemm_kchunks(p.C0 + p.C1), "igemm: kchunks mismatch");
     if (p.M == 0) return DPC_OK;
     const int mtiles = (int)((p.M + BM - 1) / BM);
+    const double flops = 2.0 * (double)p.M * p.N * (double)p.ntaps * (p.C0 + p.C1);
+    const double bytes = 4.0 * ((double)p.M * (p.N + (p.resid ? p.N : 0)) + (double)p.BF * p.Hi * p.Wi * (p.C0 + p.C1) +
+                                (double)p.ntaps * (p.C0 + p.C1) * p.N);
+    ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
     if (p.Npad % 128 == 0 && p.N > 64) {
         const int grid = mtiles * (p.Npad / 128);
         const size_t lds = 2 * (BM + 128) * LDS_STRIDE * sizeof(float);
@@ -345,6 +349,7 @@ int launch_stem(const StemParams& p, hipStream_t s) {
     const int mtiles = (int)((p.M + BM - 1) / BM);
     const int grid = mtiles * (p.Npad / 64);
     const size_t lds = 2 * (BM + 64) * LDS_STRIDE * sizeof(float);
+    ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * p.kchunks * 32, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
     static bool once = false;
     if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
     hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), lds, s, p);

@@ -50,6 +50,7 @@ int launch_ln_stats(const float* x, float* stats, long long rows, int C, hipStre
     int G = 1;
     while (G < 64 && G < C / 4) G <<= 1;   // power-of-two lanes per row
     const int rows_per_block = 4 * (64 / G);
+    ProfScope prof(PROF_LN, 0, 4.0 * (double)rows * (C + 2), s);
     const long long nb = (rows + rows_per_block - 1) / rows_per_block;
     const int grid = (int)std::min<long long>(nb, 256 * 16);
     if (grid == 0) return DPC_OK;
@@ -72,8 +73,8 @@ static int gn_chunks(long long R, int C) {
 }
 
 size_t gn_workspace_bytes(int B, int C) {
-    // fp64 partial sums [B][GN_MAX_CHUNKS][C][2]
-    return (size_t)B * GN_MAX_CHUNKS * C * 2 * sizeof(double);
+    // fp64 partial sums [B][GN_MAX_CHUNKS][C][2] + finished (mean, rstd) [B][groups<=C][2] floats
+    return (size_t)B * GN_MAX_CHUNKS * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
 }
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
@@ -111,29 +112,46 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* out, const float* resid,
-                                                       const double* __restrict__ part,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ scale_shift, long long R, int C,
-                                                       int groups, int nchunk, int nblk) {
-    __shared__ float s_mean[1024], s_rstd[1024];   // per group (groups <= 1024)
-    const int b = blockIdx.y, tid = threadIdx.x;
+// one wave per (sample, group): fold the fp64 partials into (mean, rstd)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats,
+                                                          long long R, int C, int groups, int nchunk, int B) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= B * groups) return;
+    const int b = wid / groups, g = wid % groups;
     const int cpg = C / groups;
-    for (int g = tid; g < groups; g += 256) {
-        double s = 0, q = 0;
-        for (int k = 0; k < nchunk; ++k) {
-            const double* src = part + (((long long)b * nchunk + k) * C + g * cpg) * 2;
-            for (int c = 0; c < cpg; ++c) {
-                s += src[2 * c];
-                q += src[2 * c + 1];
-            }
-        }
+    double s = 0, q = 0;
+    for (int i = lane; i < nchunk * cpg; i += 64) {
+        const int k = i / cpg, c = i % cpg;
+        const double* src = part + (((long long)b * nchunk + k) * C + g * cpg + c) * 2;
+        s += src[0];
+        q += src[1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) {
         const double n = (double)R * cpg;
         const double mean = s / n;
         double var = q / n - mean * mean;
         if (var < 0) var = 0;
-        s_mean[g] = (float)mean;
-        s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+        stats[2 * wid] = (float)mean;
+        stats[2 * wid + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* out, const float* resid,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ scale_shift, long long R, int C,
+                                                       int groups, int nblk) {
+    __shared__ float s_mean[1024], s_rstd[1024];   // per group (groups <= 1024)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups;
+    for (int g = tid; g < groups; g += 256) {
+        s_mean[g] = stats[2 * (b * groups + g)];
+        s_rstd[g] = stats[2 * (b * groups + g) + 1];
     }
     __syncthreads();
     const int tpr = C >> 2, rpp = 256 / tpr;
@@ -172,6 +190,7 @@ int launch_groupnorm_silu(const float* x, float* out, const float* resid, const 
     DPC_REQUIRE(groups >= 1 && C % groups == 0 && groups <= 1024, "groupnorm: groups must divide C");
     if (B == 0 || R == 0) return DPC_OK;
     const int nchunk = gn_chunks(R, C);
+    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * R * C * (resid ? 4 : 3), s);
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, part, R, C, nchunk);
     DPC_LAUNCH_CHECK();
@@ -179,8 +198,12 @@ int launch_groupnorm_silu(const float* x, float* out, const float* resid, const 
     long long nblk = R / ((long long)rpp * 8);
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, out, resid, part, gamma, beta,
-                       scale_shift, R, C, groups, nchunk, (int)nblk);
+    float* stats = reinterpret_cast<float*>(part + (size_t)B * GN_MAX_CHUNKS * C * 2);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s, part, stats, R, C, groups, nchunk,
+                       B);
+    DPC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, out, resid, stats, gamma, beta,
+                       scale_shift, R, C, groups, (int)nblk);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

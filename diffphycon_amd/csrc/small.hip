@@ -28,6 +28,7 @@ int launch_small_linear(const float* in, const float* W, const float* bias, floa
                         int in_act, int out_act, hipStream_t s) {
     const long long total = (long long)B * N;
     if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_SMALL, 2.0 * B * (double)N * K, 4.0 * ((double)N * K + (double)B * (N + K)), s);
     hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, in, W, bias, out, B, K,
                        N, in_act, out_act);
     DPC_LAUNCH_CHECK();

@@ -108,6 +108,8 @@ int launch_ddpm_update_smoke(const float* x, const float* eps_j, const float* ep
     const long long total = (long long)B * F * C * H * W;
     if (total == 0) return DPC_OK;
     const bool vec = ((long long)H * W) % 4 == 0;
+    // algorithmic traffic: x, eps_j, z, x_next on C channels + eps_w on 2 channels (+ x0_out)  => 26 floats / 6-ch cell
+    ProfScope prof(PROF_UPDATE, 0, 4.0 * ((double)total * (3 + (z ? 1 : 0) + (x0_out ? 1 : 0)) + (double)total / C * 2), s);
     const long long work = vec ? total / 4 : total;
     const int grid = (int)std::min<long long>((work + 255) / 256, 256 * 8);
     if (vec)
@@ -171,6 +173,7 @@ int launch_philox_normal(float* out, int B, long long per_traj, uint64_t seed, l
                          hipStream_t s) {
     const long long total = (long long)B * ((per_traj + 3) / 4);
     if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_PHILOX, 0, 4.0 * (double)B * per_traj, s);
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(philox_normal_kernel, dim3(grid), dim3(256), 0, s, out, B, per_traj, seed, traj0, draw);
     DPC_LAUNCH_CHECK();

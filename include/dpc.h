@@ -40,6 +40,19 @@ enum dpc_status {
 int dpc_version(void);
 const char* dpc_last_error(void);
 
+/* Opt-in timing of every kernel launch with HIP events on the launch stream, aggregated per kernel class
+ * (bench.py's roofline leg; no counterpart in the reference, whose only stopwatch is commented out at
+ * inference/inference_1d_burgers.py:287-291).  flops/bytes are ALGORITHMIC totals of the timed launches. */
+typedef struct {
+    const char* name;
+    int64_t launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} dpc_profile_row;
+int dpc_profile_begin(void);
+int dpc_profile_end(dpc_profile_row* rows, int max_rows, int* n_rows);
+
 /* ------------------------------------------------------------------ space-time U-Net denoiser
  * Replaces model/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py
  *   Unet3D_with_Conv3D.__init__ :357-471 (create/load), .forward :486-552 (forward).

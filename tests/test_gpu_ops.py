@@ -103,9 +103,9 @@ def test_groupnorm_silu(B, R, Cc, G, ss, dev, L):
         ref = ref * (sc[:, :, None] + 1) + sh[:, :, None]
     ref = F.silu(ref).permute(0, 2, 1).float()
     xd = x.to(dev).contiguous()
+    gd, bd, sd = gamma.to(dev), beta.to(dev), (scsh.to(dev) if ss else None)   # keep alive until the launch
     ws = L.workspace(L.lib().dpc_groupnorm_workspace_bytes(B, Cc), dev)
-    L.check(L.lib().dpc_groupnorm_silu_cl(L.ptr(xd), L.ptr(gamma.to(dev)), L.ptr(beta.to(dev)),
-                                          L.ptr(scsh.to(dev)) if ss else None, B, R, Cc, G,
+    L.check(L.lib().dpc_groupnorm_silu_cl(L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(sd), B, R, Cc, G,
                                           C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
     got = xd.cpu()
     assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5), (got - ref).abs().max()
@@ -136,8 +136,9 @@ def test_attention_core_temporal(B, Fr, HW, dev, L):
     ref = _attn_ref(qkv.permute(0, 2, 1, 3), heads, True, bias).permute(0, 2, 1, 3).contiguous()
     cos, sin = _rotary_tables(Fr, 32)
     out = torch.empty(B, Fr, HW, heads * 32, device=dev)
-    L.check(L.lib().dpc_attention_core(L.ptr(qkv.to(dev)), L.ptr(out), heads, Fr, B * HW, HW, Fr * HW, 1, HW,
-                                       L.ptr(cos.to(dev)), L.ptr(sin.to(dev)), L.ptr(bias.to(dev)), L.stream()))
+    qd, cd, sd, bd = qkv.to(dev), cos.to(dev), sin.to(dev), bias.to(dev)
+    L.check(L.lib().dpc_attention_core(L.ptr(qd), L.ptr(out), heads, Fr, B * HW, HW, Fr * HW, 1, HW,
+                                       L.ptr(cd), L.ptr(sd), L.ptr(bd), L.stream()))
     got = out.cpu()
     assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5), (got - ref).abs().max()
 
@@ -149,8 +150,8 @@ def test_attention_core_spatial(BF, N, dev, L):
     qkv = torch.randn(BF, N, 3 * heads * 32, generator=g) * 1.5
     ref = _attn_ref(qkv, heads, False, None)
     out = torch.empty(BF, N, heads * 32, device=dev)
-    L.check(L.lib().dpc_attention_core(L.ptr(qkv.to(dev)), L.ptr(out), heads, N, BF, 1, N, 0, 1, None, None, None,
-                                       L.stream()))
+    qd = qkv.to(dev)
+    L.check(L.lib().dpc_attention_core(L.ptr(qd), L.ptr(out), heads, N, BF, 1, N, 0, 1, None, None, None, L.stream()))
     got = out.cpu()
     assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5), (got - ref).abs().max()
 
@@ -167,7 +168,8 @@ def test_linear_attention_core(imgs, N, dev, L):
     ref = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(imgs, N, heads * 32).float()
     out = torch.empty(imgs, N, heads * 32, device=dev)
     ws = L.workspace(L.lib().dpc_linear_attention_workspace_bytes(imgs, heads), dev)
-    L.check(L.lib().dpc_linear_attention_core(L.ptr(qkv.to(dev)), L.ptr(out), heads, imgs, N,
+    qd = qkv.to(dev)
+    L.check(L.lib().dpc_linear_attention_core(L.ptr(qd), L.ptr(out), heads, imgs, N,
                                               C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
     got = out.cpu()
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6), (got - ref).abs().max()
@@ -180,8 +182,8 @@ def test_burgers_fd_bit_exact(dev, L):
                                         (g["u0b"], g["fb"], 0.02, 0.5, 5e-4, 4, "trajb")):
         N, nx = u0.shape
         out = torch.empty(N, nt + 1, nx, device=dev)
-        L.check(L.lib().dpc_burgers_fd(L.ptr(torch.from_numpy(u0).to(dev)), L.ptr(torch.from_numpy(f).to(dev)),
-                                       L.ptr(out), N, nx, nt, visc, T, dt, L.stream()))
+        ud, fd = torch.from_numpy(u0).to(dev), torch.from_numpy(f).to(dev)
+        L.check(L.lib().dpc_burgers_fd(L.ptr(ud), L.ptr(fd), L.ptr(out), N, nx, nt, visc, T, dt, L.stream()))
         got = out.cpu().numpy()
         # integer index schedule + fp32 stencil: bit-exact against the oracle AND against the reference fixture
         assert np.array_equal(got, OB.burgers_numeric_solve_free(u0, f, visc, T, dt, nt))
@@ -189,8 +191,8 @@ def test_burgers_fd_bit_exact(dev, L):
     # a batch that does not fill the last workgroup, synthetic inputs
     u0, f = OB.synthetic_inputs(50, 128, 10, seed=3)
     out = torch.empty(50, 11, 128, device=dev)
-    L.check(L.lib().dpc_burgers_fd(L.ptr(torch.from_numpy(u0).to(dev)), L.ptr(torch.from_numpy(f).to(dev)), L.ptr(out),
-                                   50, 128, 10, 0.01, 1.0, 1e-4, L.stream()))
+    ud, fd = torch.from_numpy(u0).to(dev), torch.from_numpy(f).to(dev)
+    L.check(L.lib().dpc_burgers_fd(L.ptr(ud), L.ptr(fd), L.ptr(out), 50, 128, 10, 0.01, 1.0, 1e-4, L.stream()))
     assert np.array_equal(out.cpu().numpy(), OB.burgers_numeric_solve_free(u0, f, 0.01, 1.0, 1e-4, 10))
 
 
