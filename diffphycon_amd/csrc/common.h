@@ -38,7 +38,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // ---------------------------------------------------------------- opt-in event timing (profile.hip)
 enum ProfClass {
     PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
-    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_NCLASS
+    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
@@ -78,7 +78,20 @@ int igemm_kchunks(int K);
 int launch_igemm(const IgemmParams& p, hipStream_t s);
 // generic weight re-pack: wp[tap][kc][n][kk] = w[n*stride_n + (kc*32+kk)*stride_c + tap_off[tap]]
 int launch_pack_weights(const float* w, float* wp, int N, int Npad, int K, int ntaps, long long stride_n,
-                        long long stride_c, const int* tap_off_host, hipStream_t s);
+                        long long stride_c, const int* tap_off_host, hipStream_t s, int bk = 32);
+
+// Conv3d 3x3x3 stride 1 pad 1 with the LDS-staged halo tile (conv3h.hip); weights packed with bk = 16
+struct Conv3hParams {
+    const float* a0;        // channels-last [B,F,H,W,C0]
+    const float* a1;        // virtual concat source [B,F,H,W,C1] or null
+    int C0, C1;
+    const float* wp;        // [27][kchunks][Npad][16]
+    const float* bias;
+    float* out;             // channels-last [B,F,H,W,N]
+    int B, F, H, W;
+    int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
+};
+int launch_conv3h(const Conv3hParams& p, hipStream_t s);
 
 // "gather" variant for the 7x7x7 stem on the reference-layout input [BF, C, H, W] (K = taps*C flattened)
 struct StemParams {

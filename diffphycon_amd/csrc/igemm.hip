@@ -231,32 +231,33 @@ int launch_igemm(const IgemmParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------------ weight packing
 struct PackTaps { int off[32]; };
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int Npad, int K,
-                                    int kchunks, int ntaps, long long stride_n, long long stride_c, PackTaps t) {
-    const long long total = (long long)ntaps * kchunks * Npad * BK;
+                                    int kchunks, int ntaps, long long stride_n, long long stride_c, PackTaps t, int bk) {
+    const long long total = (long long)ntaps * kchunks * Npad * bk;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int kk = (int)(i % BK);
-        long long r = i / BK;
+        const int kk = (int)(i % bk);
+        long long r = i / bk;
         const int n = (int)(r % Npad);
         r /= Npad;
         const int kc = (int)(r % kchunks);
         const int tap = (int)(r / kchunks);
-        const int c = kc * BK + kk;
+        const int c = kc * bk + kk;
         float v = 0.f;
         if (n < N && c < K) v = w[n * stride_n + c * stride_c + t.off[tap]];
         wp[i] = v;
     }
 }
 
+// wp[tap][kc][n][bk] with kc over ceil(K/bk) chunks (bk = 32 for igemm, 16 for conv3h)
 int launch_pack_weights(const float* w, float* wp, int N, int Npad, int K, int ntaps, long long stride_n,
-                        long long stride_c, const int* tap_off_host, hipStream_t s) {
+                        long long stride_c, const int* tap_off_host, hipStream_t s, int bk) {
     DPC_REQUIRE(ntaps <= 32, "pack: at most 32 taps");
     PackTaps t;
     for (int i = 0; i < 32; ++i) t.off[i] = i < ntaps ? tap_off_host[i] : 0;
-    const int kchunks = igemm_kchunks(K);
-    const long long total = (long long)ntaps * kchunks * Npad * BK;
+    const int kchunks = (K + bk - 1) / bk;
+    const long long total = (long long)ntaps * kchunks * Npad * bk;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(256), 0, s, w, wp, N, Npad, K, kchunks, ntaps, stride_n,
-                       stride_c, t);
+                       stride_c, t, bk);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

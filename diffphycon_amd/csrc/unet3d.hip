@@ -28,6 +28,7 @@ struct PackedConv {
     DevBuf wp;
     int N = 0, Npad = 0, K = 0, kchunks = 0, ntaps = 0;
     int sh = 1, sw = 1;
+    bool halo = false;      // 3x3x3 stride-1 conv: packed with bk = 16 for the LDS halo-tile kernel (conv3h.hip)
     signed char tdf[32], tdh[32], tdw[32];
 };
 
@@ -151,9 +152,12 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
                 pc.tdw[t] = (signed char)(c - pw);
                 off[t] = t;
             }
-    int rc = pc.wp.alloc((size_t)ntaps * pc.kchunks * pc.Npad * 32 * sizeof(float));
+    pc.halo = (kd == 3 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1);
+    const int bk = pc.halo ? 16 : 32;
+    pc.kchunks = (K + bk - 1) / bk;
+    int rc = pc.wp.alloc((size_t)ntaps * pc.kchunks * pc.Npad * bk * sizeof(float));
     if (rc) return rc;
-    return launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s);
+    return launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s, bk);
 }
 
 // One output-parity class (a,b) of ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1), weight [K][N][1][4][4]:
@@ -180,6 +184,13 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
              const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s) {
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
+    if (pc.halo) {
+        DPC_REQUIRE(!resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo, "conv3h: plain 3x3x3 conv only");
+        Conv3hParams q{};
+        q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = pc.wp.f(); q.bias = bias; q.out = out;
+        q.B = BF / F; q.F = F; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = pc.kchunks;
+        return launch_conv3h(q, s);
+    }
     IgemmParams p{};
     p.a0 = a0; p.a1 = a1; p.C0 = C0; p.C1 = C1;
     p.wp = pc.wp.f(); p.bias = bias; p.resid = resid; p.out = out;
