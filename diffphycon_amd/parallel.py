@@ -1,0 +1,38 @@
+"""Batch sharding over ranks (one process per GPU; `torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  Trajectories are independent, so the only exchanges are the final
+gather of per-trajectory metric rows and the max-over-ranks of the elapsed time; nothing is exchanged inside the
+sampling loop."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch, rank, world_size):
+    """Contiguous split of trajectories [0, global_batch): rank r owns [start, stop). Remainders go to the low ranks."""
+    base, rem = divmod(global_batch, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def gather_metric_rows(rows):
+    """rows: [B_local, M] per rank (B_local may differ) -> [B_global, M] on every rank, in global trajectory order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows
+    world = dist.get_world_size()
+    n = torch.tensor([rows.shape[0]], dtype=torch.long, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts)
+    buf = torch.zeros((pad,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    buf[: rows.shape[0]] = rows
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def max_over_ranks(seconds, device):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
