@@ -38,7 +38,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // ---------------------------------------------------------------- opt-in event timing (profile.hip)
 enum ProfClass {
     PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
-    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_NCLASS
+    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
@@ -92,6 +92,23 @@ struct Conv3hParams {
     int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
 };
 int launch_conv3h(const Conv3hParams& p, hipStream_t s);
+
+// Fused Residual(PreNorm(temporal Attention)) (tattn_fused.hip); weights in the reference layout
+struct TattnParams {
+    const float* x;         // channels-last [B,F,HW,C]
+    float* out;             // may alias x
+    const float* gamma;     // [C]
+    const float* wqkv;      // to_qkv.weight [384][C]
+    const float* wout;      // to_out.weight [C][128]
+    const float* rot_cos;   // [F][32]
+    const float* rot_sin;
+    const float* bias;      // [4][F][F]
+    long long npix;         // B*HW sequences
+    long long HW;
+    int F;
+};
+bool tattn_fused_supported(int C, int F, int heads);
+int launch_tattn_fused(const TattnParams& p, int C, hipStream_t s);
 
 // "gather" variant for the 7x7x7 stem on the reference-layout input [BF, C, H, W] (K = taps*C flattened)
 struct StemParams {

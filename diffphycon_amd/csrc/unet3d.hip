@@ -64,6 +64,7 @@ struct dpc_unet3d_s {
     int frames = 0;
     dpc::DevBuf t_bias, t_cos, t_sin, t_freq;
     bool finalized = false;
+    bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 selects the unfused reference composition (A/B tests)
     // debug taps
     bool taps_on = false;
     struct Tap { std::unique_ptr<dpc::DevBuf> buf; size_t floats = 0; };
@@ -309,6 +310,14 @@ struct Runner {
         const long long P = (long long)mb * F * Hl * Wl;
         const int HD = h->cfg.attn_heads * 32;
         const long long HWl = (long long)Hl * Wl;
+        if (temporal && h->fused_attn && tattn_fused_supported(C, F, h->cfg.attn_heads)) {
+            TattnParams tp{};
+            tp.x = x; tp.out = x; tp.gamma = raw(p + ".fn.norm.gamma"); tp.wqkv = raw(p + ".fn.fn.fn.to_qkv.weight");
+            tp.wout = raw(p + ".fn.fn.fn.to_out.weight"); tp.rot_cos = h->t_cos.f(); tp.rot_sin = h->t_sin.f();
+            tp.bias = h->t_bias.f(); tp.npix = (long long)mb * HWl; tp.HW = HWl; tp.F = F;
+            RUN(launch_tattn_fused(tp, C, s));
+            return;
+        }
         const size_t m = ar.mark();
         float* stats = ar.allocf(P * 2);
         float* qkv = ar.allocf(P * 3 * HD);
@@ -467,6 +476,7 @@ int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out) {
     DPC_REQUIRE(cfg->channels >= 1 && cfg->channels <= 255, "unet3d: channels");
     auto* h = new dpc_unet3d_s();
     h->cfg = *cfg;
+    if (const char* e = getenv("DPC_UNFUSED_ATTN")) h->fused_attn = !(e[0] == '1');
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
     for (int i = 0; i < cfg->n_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);
@@ -517,6 +527,10 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
         auto pc = std::make_unique<PackedConv>();
         rc = pack_conv3d(*pc, w, (int)shape[0], (int)shape[1], 1, 1, 1, 1, 1, 0, 0, 0, s);   // Linear / Conv2d 1x1: [N][K]
         h->conv[name] = std::move(pc);
+        auto b = std::make_unique<DevBuf>();                 // reference layout too (fused attention kernel)
+        if (!rc && (rc = b->alloc((size_t)numel * sizeof(float)))) return rc;
+        DPC_HIP(hipMemcpyAsync(b->p, w, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        h->raw[name] = std::move(b);
     } else {
         auto b = std::make_unique<DevBuf>();
         if ((rc = b->alloc((size_t)numel * sizeof(float)))) return rc;

@@ -90,6 +90,26 @@ def test_unet3d_full_width_vs_oracle(channels, seed, dev):
     assert err < 2e-4, err
 
 
+def test_fused_temporal_attention_equals_unfused_composition(dev, monkeypatch):
+    """tattn_fused.hip (LN + qkv + rotary + softmax + PV + to_out + residual in one kernel, C = 64 / 128) against the
+    unfused kernels (ln_stats -> igemm -> attention_core -> igemm) on the same weights, F = 32 and a ragged F = 20."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=4)
+    for frames in (32, 20):
+        x = torch.randn(1, frames, 6, 8, 8, generator=torch.Generator().manual_seed(frames)).to(dev)
+        t = torch.tensor([17], device=dev)
+        outs = []
+        for unfused in ("0", "1"):
+            monkeypatch.setenv("DPC_UNFUSED_ATTN", unfused)
+            m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2), channels=6)
+            m.load_state_dict(sd)
+            outs.append(m.to(dev)(x, t))
+        err = ((outs[0] - outs[1]).abs().max() / outs[1].abs().max()).item()
+        assert err < 2e-5, (frames, err)
+
+
 def test_unet3d_channel_view_input(dev):
     """The prior model reads x[:, :, 3:5] of the joint state in place."""
     g = load_golden("unet3d_w")
