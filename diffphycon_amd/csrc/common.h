@@ -38,7 +38,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // ---------------------------------------------------------------- opt-in event timing (profile.hip)
 enum ProfClass {
     PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
-    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_NCLASS
+    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_LATTN_FUSED, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
@@ -107,6 +107,21 @@ struct TattnParams {
     long long HW;
     int F;
 };
+// Fused Residual(PreNorm(SpatialLinearAttention)) (lattn_fused.hip); weights in the reference layout
+struct LattnParams {
+    const float* x;         // channels-last [images, N, C]
+    float* out;             // may alias x
+    const float* gamma;     // [C]
+    const float* wqkv;      // to_qkv.weight [384][C] (Conv2d 1x1)
+    const float* wout;      // to_out.weight [C][128]
+    const float* bout;      // to_out.bias [C]
+    float* ctx;             // workspace [images][4][32][32]
+    long long images;
+    int N;
+};
+bool lattn_fused_supported(int C, int heads);
+size_t lattn_fused_workspace_bytes(long long images);
+int launch_lattn_fused(const LattnParams& p, int C, hipStream_t s);
 bool tattn_fused_supported(int C, int F, int heads);
 int launch_tattn_fused(const TattnParams& p, int C, hipStream_t s);
 

@@ -21,7 +21,7 @@ constexpr int KC = 16;
 constexpr int AST = 20;                    // LDS floats per halo point / per weight row
 constexpr int HLOADS = (NHALO * 4 + 255) / 256;   // float4 loads per thread per chunk (6)
 
-template <int BN>
+template <int BN, bool BDIRECT>
 __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
     constexpr int NT = BN / 64;
     constexpr int BL = BN / 64;            // weight float4 loads per thread per (tap, chunk)
@@ -109,6 +109,57 @@ __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
     const int a_lane = abase * AST + 4 * hh;
     const int b_lane = (wn * (BN / 2) + l31) * AST + 4 * hh;
 
+    if constexpr (BDIRECT) {
+        // Variant: weight fragments straight from global/L2 into registers (4 KB per (tap, chunk), shared by every
+        // workgroup, L1/L2 resident), prefetched one tap ahead: no LDS staging and NO barrier inside the tap loop.
+        const float* wlane = p.wp + ((long long)n0 + wn * (BN / 2) + l31) * KC + 4 * hh;
+        f32x4 wc[NT][2], wn_[NT][2];
+        auto ldw = [&](int tap, int kc, f32x4 (&w)[NT][2]) {
+            const float* src = wlane + ((long long)tap * p.kchunks + kc) * p.Npad * KC;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) w[nt][j] = *reinterpret_cast<const f32x4*>(src + nt * 32 * KC + 8 * j);
+        };
+        load_halo(0);
+        ldw(0, 0, wc);
+        store_halo();
+        __syncthreads();
+        for (int kc = 0; kc < p.kchunks; ++kc) {
+            const bool more_kc = kc + 1 < p.kchunks;
+            if (more_kc) load_halo(kc + 1);
+#pragma unroll 3
+            for (int tap = 0; tap < 27; ++tap) {
+                const bool last_tap = tap == 26;
+                if (!last_tap || more_kc) ldw(last_tap ? 0 : tap + 1, last_tap ? kc + 1 : kc, wn_);
+                const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+                const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * AST;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 a[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        a[mt] = *reinterpret_cast<const f32x4*>(&halo[aoff + mt * (HH * HWD * AST) + 8 * j]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], wc[nt][j][s], acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) wc[nt][j] = wn_[nt][j];
+            }
+            if (more_kc) {
+                __syncthreads();
+                store_halo();
+                __syncthreads();
+            }
+        }
+    } else {
     load_halo(0);
     load_b(0, 0);
     store_halo();
@@ -150,6 +201,7 @@ __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
             }
         }
     }
+    }   // !BDIRECT
 
     // ---- epilogue: + bias, channels-last store
 #pragma unroll
@@ -182,17 +234,26 @@ int launch_conv3h(const Conv3hParams& p, hipStream_t s) {
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     ProfScope prof(wide ? PROF_CONV3H128 : PROF_CONV3H64, flops, bytes, s);
+    static const int bdirect = [] { const char* e = getenv("DPC_CONV3H_BDIRECT"); return e ? atoi(e) : 0; }();
     if (wide) {
         const long long grid = tiles * (p.Npad / 128);
         DPC_REQUIRE(grid < (1ll << 31), "conv3h: grid too large");
-        const size_t lds = (NHALO * AST + 2 * 128 * AST) * sizeof(float);
-        hipLaunchKernelGGL(conv3h_kernel<128>, dim3((unsigned)grid), dim3(256), lds, s, p);
+        if (bdirect) {
+            hipLaunchKernelGGL((conv3h_kernel<128, true>), dim3((unsigned)grid), dim3(256), NHALO * AST * sizeof(float), s, p);
+        } else {
+            const size_t lds = (NHALO * AST + 2 * 128 * AST) * sizeof(float);
+            hipLaunchKernelGGL((conv3h_kernel<128, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+        }
     } else {
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3h: Npad must be a multiple of 64");
         const long long grid = tiles * (p.Npad / 64);
         DPC_REQUIRE(grid < (1ll << 31), "conv3h: grid too large");
-        const size_t lds = (NHALO * AST + 2 * 64 * AST) * sizeof(float);
-        hipLaunchKernelGGL(conv3h_kernel<64>, dim3((unsigned)grid), dim3(256), lds, s, p);
+        if (bdirect) {
+            hipLaunchKernelGGL((conv3h_kernel<64, true>), dim3((unsigned)grid), dim3(256), NHALO * AST * sizeof(float), s, p);
+        } else {
+            const size_t lds = (NHALO * AST + 2 * 64 * AST) * sizeof(float);
+            hipLaunchKernelGGL((conv3h_kernel<64, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+        }
     }
     DPC_LAUNCH_CHECK();
     return DPC_OK;

@@ -286,6 +286,17 @@ struct Runner {
     void spatial_linear(const std::string& p, float* x, int C, int Hl, int Wl) {
         const long long P = (long long)mb * F * Hl * Wl;
         const int HD = h->cfg.attn_heads * 32;
+        if (h->fused_attn && lattn_fused_supported(C, h->cfg.attn_heads)) {
+            const size_t m0 = ar.mark();
+            LattnParams lp{};
+            lp.ctx = reinterpret_cast<float*>(ar.alloc(lattn_fused_workspace_bytes((long long)mb * F)));
+            lp.x = x; lp.out = x; lp.gamma = raw(p + ".fn.norm.gamma"); lp.wqkv = raw(p + ".fn.fn.to_qkv.weight");
+            lp.wout = raw(p + ".fn.fn.to_out.weight"); lp.bout = raw(p + ".fn.fn.to_out.bias");
+            lp.images = (long long)mb * F; lp.N = Hl * Wl;
+            RUN(launch_lattn_fused(lp, C, s));
+            ar.release(m0);
+            return;
+        }
         const size_t m = ar.mark();
         float* stats = ar.allocf(P * 2);
         float* qkv = ar.allocf(P * 3 * HD);
