@@ -15,11 +15,26 @@
 namespace dpc {
 
 constexpr int TF = 4, TH = 4, TW = 8;
-constexpr int HF = TF + 2, HH = TH + 2, HWD = TW + 2;
-constexpr int NHALO = HF * HH * HWD;       // 360
+constexpr int HF = TF + 2, HH = TH + 2, HWL = TW + 2;      // logical halo extent 6 x 6 x 10
+constexpr int HWD = 12;                    // halo row PITCH in LDS: 12 (not 10) makes every ds_read_b128 lane group of
+                                           // the A fragment hit 16 distinct bank groups for all 27 taps (see lane_hw)
+constexpr int NLOG = HF * HH * HWL;        // 360 points loaded
+constexpr int NHALO = HF * HH * HWD;       // 432 point slots allocated
 constexpr int KC = 16;
 constexpr int AST = 20;                    // LDS floats per halo point / per weight row
-constexpr int HLOADS = (NHALO * 4 + 255) / 256;   // float4 loads per thread per chunk (6)
+constexpr int HLOADS = (NLOG * 4 + 255) / 256;    // float4 loads per thread per chunk (6)
+
+// MFMA tile row i (0..31) -> output point (h, w) of the 4 x 8 tile.  ds_read_b128 services lanes in the groups
+// {0-3,12-15,20-27} and {4-11,16-19,28-31}; with pitch 12 the rows {0,2} / {1,3} each cover all 16 residues of
+// (12 h + w) mod 16, so assigning rows 0,2 to the first group and 1,3 to the second is conflict-free under any tap shift.
+__device__ __forceinline__ void lane_hw(int i, int& h, int& w) {
+    if (i < 4) { h = 0; w = i; }
+    else if (i < 12) { h = 1; w = i - 4; }
+    else if (i < 16) { h = 0; w = i - 8; }
+    else if (i < 20) { h = 3; w = i - 16; }
+    else if (i < 28) { h = 2; w = i - 20; }
+    else { h = 3; w = i - 24; }
+}
 
 template <int BN, bool BDIRECT>
 __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
@@ -54,9 +69,9 @@ __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
     for (int i = 0; i < HLOADS; ++i) {
         const int q = tid + 256 * i;
         const int pt = q >> 2;
-        const int pf = pt / (HH * HWD), ph = (pt / HWD) % HH, pw = pt % HWD;
+        const int pf = pt / (HH * HWL), ph = (pt / HWL) % HH, pw = pt % HWL;
         const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
-        hok[i] = pt < NHALO && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        hok[i] = pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
         hoff[i] = (((long long)b * p.F + f) * p.H + h) * p.W + w;
     }
     const int hslot = (tid & 3) * 4;
@@ -80,7 +95,9 @@ __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             const int q = tid + 256 * i;
-            if (q < NHALO * 4) *reinterpret_cast<f32x4*>(&halo[(q >> 2) * AST + hslot]) = hreg[i];
+            const int pt = q >> 2;
+            const int phys = (pt / HWL) * HWD + pt % HWL;          // (pf*HH + ph) * pitch + pw
+            if (q < NLOG * 4) *reinterpret_cast<f32x4*>(&halo[phys * AST + hslot]) = hreg[i];
         }
     };
     // ---- weights: wp[tap][kc][n][16]; thread -> row (tid>>2) + 64 i, float4 slot tid&3
@@ -105,7 +122,9 @@ __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     // A fragment base (halo coordinates of this lane's output point, tap (0,0,0)): frame wm*2+mt, row l31>>3, col l31&7
-    const int abase = ((wm * 2) * HH + (l31 >> 3)) * HWD + (l31 & 7);
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    const int abase = ((wm * 2) * HH + lh) * HWD + lw;
     const int a_lane = abase * AST + 4 * hh;
     const int b_lane = (wn * (BN / 2) + l31) * AST + 4 * hh;
 
@@ -216,7 +235,9 @@ __global__ __launch_bounds__(256, 3) void conv3h_kernel(Conv3hParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;     // row inside the 32-row MFMA tile = (h, w)
-                const int h = h0 + (i >> 3), w = w0 + (i & 7);
+                int ih, iw;
+                lane_hw(i, ih, iw);
+                const int h = h0 + ih, w = w0 + iw;
                 if (h < p.H && w < p.W)
                     p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][nt][r] + bv;
             }
@@ -234,7 +255,10 @@ int launch_conv3h(const Conv3hParams& p, hipStream_t s) {
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     ProfScope prof(wide ? PROF_CONV3H128 : PROF_CONV3H64, flops, bytes, s);
-    static const int bdirect = [] { const char* e = getenv("DPC_CONV3H_BDIRECT"); return e ? atoi(e) : 0; }();
+    // weights: BN=128 reads fragments straight from L2 (keeps LDS at 34.5 KB -> 4 workgroups/CU by LDS); BN=64 stages
+    // them through LDS.  Both variants measure the same throughput; DPC_CONV3H_BDIRECT=0/1 forces one (A/B tests).
+    static const int bforce = [] { const char* e = getenv("DPC_CONV3H_BDIRECT"); return e ? atoi(e) : -1; }();
+    const int bdirect = bforce >= 0 ? bforce : (wide ? 1 : 0);
     if (wide) {
         const long long grid = tiles * (p.Npad / 128);
         DPC_REQUIRE(grid < (1ll << 31), "conv3h: grid too large");
