@@ -62,11 +62,16 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
     p.N = Cout; p.Npad = igemm_npad(Cout); p.kchunks = igemm_kchunks(Cin); p.ntaps = ntaps;
     if (kd == 3 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pd == 1 && ph == 1 && pw == 1) {
         // the U-Net's 3x3x3 convs run on the LDS halo-tile kernel (conv3h.hip)
-        int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, 27, (long long)Cin * 27, 27, off, s, 16);
-        if (rc) return rc;
         Conv3hParams q{};
         q.a0 = x_cl; q.C0 = Cin; q.wp = wp; q.bias = bias; q.out = out_cl;
         q.B = B; q.F = F; q.H = H; q.W = W; q.N = Cout; q.Npad = p.Npad; q.kchunks = (Cin + 15) / 16;
+        if (conv_mode_default() == 1) {
+            int rc = launch_pack_weights_x6(w_ref, wp, Cout, p.Npad, Cin, s);     // 96 B per (tap, chunk, n) <= fp32 pack size
+            if (rc) return rc;
+            return launch_conv3x6(q, s);
+        }
+        int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, 27, (long long)Cin * 27, 27, off, s, 16);
+        if (rc) return rc;
         return launch_conv3h(q, s);
     }
     int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s);

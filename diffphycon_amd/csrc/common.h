@@ -38,7 +38,8 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // ---------------------------------------------------------------- opt-in event timing (profile.hip)
 enum ProfClass {
     PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
-    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_LATTN_FUSED, PROF_NCLASS
+    PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_LATTN_FUSED, PROF_CONV3X6_64,
+    PROF_CONV3X6_128, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
@@ -92,6 +93,12 @@ struct Conv3hParams {
     int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
 };
 int launch_conv3h(const Conv3hParams& p, hipStream_t s);
+// same op on the bf16 matrix cores with an exact 3-way bf16 split of both operands (conv3x6.hip); p.wp then points to
+// the pre-split weights [27][kchunks][Npad][3][16] bf16 made by launch_pack_weights_x6
+int launch_conv3x6(const Conv3hParams& p, hipStream_t s);
+int launch_pack_weights_x6(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
+// 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6); env DPC_CONV_MODE=f32|x6, default x6
+int conv_mode_default();
 
 // Fused Residual(PreNorm(temporal Attention)) (tattn_fused.hip); weights in the reference layout
 struct TattnParams {

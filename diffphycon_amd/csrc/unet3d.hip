@@ -29,6 +29,7 @@ struct PackedConv {
     int N = 0, Npad = 0, K = 0, kchunks = 0, ntaps = 0;
     int sh = 1, sw = 1;
     bool halo = false;      // 3x3x3 stride-1 conv: packed with bk = 16 for the LDS halo-tile kernel (conv3h.hip)
+    DevBuf wp6;             // ... and pre-split into 3 bf16 planes for the bf16x6 kernel (conv3x6.hip)
     signed char tdf[32], tdh[32], tdw[32];
 };
 
@@ -158,7 +159,10 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     pc.kchunks = (K + bk - 1) / bk;
     int rc = pc.wp.alloc((size_t)ntaps * pc.kchunks * pc.Npad * bk * sizeof(float));
     if (rc) return rc;
-    return launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s, bk);
+    rc = launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s, bk);
+    if (rc || !pc.halo) return rc;
+    if ((rc = pc.wp6.alloc((size_t)27 * pc.kchunks * pc.Npad * 96))) return rc;
+    return launch_pack_weights_x6(w, pc.wp6.p, N, pc.Npad, K, s);
 }
 
 // One output-parity class (a,b) of ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1), weight [K][N][1][4][4]:
@@ -190,6 +194,10 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         Conv3hParams q{};
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = pc.wp.f(); q.bias = bias; q.out = out;
         q.B = BF / F; q.F = F; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = pc.kchunks;
+        if (conv_mode_default() == 1) {
+            q.wp = reinterpret_cast<const float*>(pc.wp6.p);
+            return launch_conv3x6(q, s);
+        }
         return launch_conv3h(q, s);
     }
     IgemmParams p{};
