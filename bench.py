@@ -27,6 +27,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3         # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # same guide: v_mfma_f32_32x32x16_bf16 dense peak
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    the guide's gfx950 correction, + WRITE_SIZE), or None when no PMC summary exists for that kernel class."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path)).get(kernel_class, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 STEPS_PER_TRAJECTORY = 1000
 LOCAL_BATCH = 64
 FRAMES, SIZE = 32, 64
@@ -174,8 +185,13 @@ def main():
         name, d = dom
         if d["flops"] > 0:
             achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
+            # conv3x6: every fp32 product costs 6 bf16 MFMAs (exact 3-way split of both operands), so the roof for
+            # ALGORITHMIC fp32 flops on that kernel is the dense bf16 MFMA peak / 6; native-fp32 kernels: 157.3 TF
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if name.startswith("conv3x6") else PEAK_FP32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": pmc_traffic(name),
+                    "peak_note": ("2500 TF bf16 dense / 6 MFMAs per fp32 product (bf16x6 split)"
+                                  if name.startswith("conv3x6") else "fp32 MFMA dense")}
         else:
             achieved = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -193,6 +209,9 @@ def main():
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 in/out and fp32 accumulate everywhere; 3x3x3 convs evaluate each fp32 product as 6 exact "
+                          "bf16 partial products (3-way split, error <= native fp32 MFMA; DPC_CONV_MODE=f32 selects the "
+                          "native fp32 MFMA kernel), all other kernels native fp32 MFMA",
             "config": {"workload": "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames, 1000-step guided DDPM, "
                                    f"batch={B} per GPU; one step = joint+prior Unet3D(dim 64, mults 1-2-4) forward + "
                                    "fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",

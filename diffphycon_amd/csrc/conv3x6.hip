@@ -61,8 +61,8 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     // LDS (63/77 KB) admits 2 workgroups/CU
+template <int BN, bool BDIRECT>
+__global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     // 3 waves/SIMD would spill (168 VGPR cap)     // LDS (63/77 KB) admits 2 workgroups/CU
     using namespace x6;
     constexpr int NT = BN / 64;
     constexpr int BQ = BN * 12 / 256;      // 8-byte weight pieces per thread per (tap, chunk): 3 (BN=64) or 6
@@ -159,6 +159,61 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
     const int a_lane = (((wm * 2) * HH + lh) * HWD + lw) * PST + hh * 16;
     const int b_lane = (wn * (BN / 2) + l31) * PST + hh * 16;
 
+    if constexpr (BDIRECT) {
+        // weight fragments straight from L2/L1 into registers, one tap ahead; no barrier inside the tap loop
+        const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
+                                     ((long long)n0 + wn * (BN / 2) + l31) * 96 + hh * 16;
+        bf16x8 wc[NT][3], wnx[NT][3];
+        auto ldw = [&](int tap, int kc, bf16x8 (&w)[NT][3]) {
+            const unsigned char* src = wlane + ((long long)tap * p.kchunks + kc) * p.Npad * 96;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) w[nt][pl] = *reinterpret_cast<const bf16x8*>(src + nt * 32 * 96 + pl * 32);
+        };
+        load_halo(0);
+        ldw(0, 0, wc);
+        store_halo();
+        __syncthreads();
+        for (int kc = 0; kc < p.kchunks; ++kc) {
+            const bool more_kc = kc + 1 < p.kchunks;
+            if (more_kc) load_halo(kc + 1);
+            for (int tap = 0; tap < 27; ++tap) {
+                const bool last_tap = tap == 26;
+                if (!last_tap || more_kc) ldw(last_tap ? 0 : tap + 1, last_tap ? kc + 1 : kc, wnx);
+                const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+                const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[mt][pl] = *reinterpret_cast<const bf16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        f32x16 c = acc[mt][nt];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], wc[nt][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], wc[nt][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][2], wc[nt][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], wc[nt][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][1], wc[nt][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][0], wc[nt][0], c, 0, 0, 0);
+                        acc[mt][nt] = c;
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wc[nt][pl] = wnx[nt][pl];
+            }
+            if (more_kc) {
+                __syncthreads();
+                store_halo();
+                __syncthreads();
+            }
+        }
+    } else {
     load_halo(0);
     load_b(0, 0);
     store_halo();
@@ -209,6 +264,8 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
         }
     }
 
+    }   // !BDIRECT
+
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
@@ -251,21 +308,28 @@ int launch_conv3x6(const Conv3hParams& p, hipStream_t s) {
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
+    static const int bdirect = [] { const char* e = getenv("DPC_CONV3X6_BDIRECT"); return e ? atoi(e) : 1; }();   // default: direct (measured faster: no per-tap barrier)
     if (wide) {
         const long long grid = tiles * (p.Npad / 128);
         DPC_REQUIRE(grid < (1ll << 31), "conv3x6: grid too large");
-        const size_t lds = (size_t)NSLOT * PST + 2 * 128 * PST;
-        static bool once = false;
-        if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-        hipLaunchKernelGGL(conv3x6_kernel<128>, dim3((unsigned)grid), dim3(256), lds, s, p);
+        if (bdirect) {
+            hipLaunchKernelGGL((conv3x6_kernel<128, true>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        } else {
+            const size_t lds = (size_t)NSLOT * PST + 2 * 128 * PST;
+            static bool once = false;
+            if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+            hipLaunchKernelGGL((conv3x6_kernel<128, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+        }
     } else {
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
         const long long grid = tiles * (p.Npad / 64);
         DPC_REQUIRE(grid < (1ll << 31), "conv3x6: grid too large");
-        const size_t lds = (size_t)NSLOT * PST + 2 * 64 * PST;
-        static bool once64 = false;
-        if (!once64) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once64 = true; }
-        hipLaunchKernelGGL(conv3x6_kernel<64>, dim3((unsigned)grid), dim3(256), lds, s, p);
+        if (bdirect) {
+            hipLaunchKernelGGL((conv3x6_kernel<64, true>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        } else {
+            const size_t lds = (size_t)NSLOT * PST + 2 * 64 * PST;
+            hipLaunchKernelGGL((conv3x6_kernel<64, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+        }
     }
     DPC_LAUNCH_CHECK();
     return DPC_OK;
