@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Turns two rocprofv3 --pmc passes (FETCH_SIZE in one, WRITE_SIZE in the other; they do not fit one pass, see
+/opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots") into profiles/pmc_traffic.json:
+
+    {profile class: {"hbm_bytes_per_launch": ..., "fetch_kb_raw": ..., "write_kb_raw": ..., "launches": ...}}
+
+Corrections per that guide's HBM section: FETCH_SIZE is reported in KB and, on gfx950, at exactly half of the bytes
+of a wide coalesced read -> x2; WRITE_SIZE (KB) is taken as is (uncalibrated, stated in the JSON).
+
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+# kernel symbol -> bench.py / ProfScope class name
+CLASSES = [
+    (r"conv3x6_kernel<128", "conv3x6_bn128"), (r"conv3x6_kernel<64", "conv3x6_bn64"),
+    (r"conv3h_kernel<128", "conv3h_bn128"), (r"conv3h_kernel<64", "conv3h_bn64"),
+    (r"igemm_kernel<128", "igemm_bn128"), (r"igemm_kernel<64", "igemm_bn64"),
+    (r"stem_kernel", "stem_gather"), (r"tattn_fused_kernel", "temporal_attention_fused"),
+    (r"lattn_(ctx|out)_kernel", "linear_attention_fused"), (r"gn_(partial|finalize|apply)_kernel", "groupnorm_silu"),
+    (r"ln_stats_kernel", "ln_stats"), (r"ddpm_update_smoke_kernel", "ddpm_update"),
+    (r"philox_normal_kernel", "philox_normal"), (r"attention_kernel", "attention_core"),
+    (r"unet2d|conv2d", "unet2d"), (r"cg_|pressure|advect|smoke_", "smoke_rollout"), (r"burgers", "burgers"),
+]
+
+
+def classify(name):
+    for pat, cls in CLASSES:
+        if re.search(pat, name):
+            return cls
+    return None
+
+
+def read(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            cls = classify(row["Kernel_Name"])
+            if cls is None:
+                continue
+            a = acc[cls]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return acc
+
+
+def sq_summary(path, dst):
+    """SQ pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) -> per-class MFMA-pipe utilisation.
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over all 256 CUs x 4 SIMDs."""
+    acc, n, dur = defaultdict(lambda: defaultdict(float)), defaultdict(int), defaultdict(float)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            cls = classify(row["Kernel_Name"])
+            if cls is None:
+                continue
+            acc[cls][row["Counter_Name"]] += float(row["Counter_Value"])
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                n[cls] += 1
+                dur[cls] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    out = {}
+    for cls, v in sorted(acc.items()):
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        out[cls] = {"launches": n[cls], "avg_us": dur[cls] / n[cls] / 1e3,
+                    "shader_clock_ghz": cyc / max(dur[cls], 1),
+                    "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4) if cyc else 0.0}
+        print(f"{cls:28s} launches {n[cls]:6d} avg {out[cls]['avg_us']:9.1f} us  clock {out[cls]['shader_clock_ghz']:.2f} GHz"
+              f"  MFMA busy {100 * out[cls]['mfma_busy_frac']:5.1f} %")
+    out["_note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; mfma_busy_frac = MFMA busy cycles / "
+                    "(GRBM_GUI_ACTIVE/8 XCDs x 256 CUs x 4 SIMDs); clock = active cycles per XCD / kernel duration")
+    json.dump(out, open(dst, "w"), indent=1)
+
+
+def main():
+    if sys.argv[1] == "sq":
+        return sq_summary(sys.argv[2], sys.argv[3])
+    fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for cls in sorted(set(fetch) | set(write)):
+        fk, fn = fetch.get(cls, [0.0, 0])
+        wk, wn = write.get(cls, [0.0, 0])
+        n = max(fn, wn, 1)
+        out[cls] = {"launches": n, "fetch_kb_raw_per_launch": fk / max(fn, 1), "write_kb_raw_per_launch": wk / max(wn, 1),
+                    "hbm_bytes_per_launch": (2.0 * fk / max(fn, 1) + wk / max(wn, 1)) * 1024.0}
+    out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 correction, "
+                    "MI355X_MICROARCH.md HBM section), KB -> bytes; WRITE_SIZE uncalibrated; averages over all launches "
+                    "of the class in the profiled bench run")
+    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    for k, v in out.items():
+        if k != "_note":
+            print(f"{k:28s} launches {v['launches']:6d}  HBM {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
+
+
+if __name__ == "__main__":
+    main()
