@@ -24,6 +24,19 @@ class Unet3DCfg(C.Structure):
                 ("init_kernel", C.c_int32), ("groups", C.c_int32), ("micro_batch", C.c_int32)]
 
 
+class SmokeDomain(C.Structure):
+    """dpc_smoke_domain (include/dpc.h)."""
+    _fields_ = [("n", C.c_int32), ("rim", C.c_int32), ("n_buckets", C.c_int32), ("target_bucket", C.c_int32),
+                ("bucket_rect", (C.c_int32 * 4) * 8), ("fluid_d", C.c_void_p), ("active_d", C.c_void_p)]
+
+
+class SmokeOut(C.Structure):
+    """dpc_smoke_out (include/dpc.h)."""
+    _fields_ = [("densitys", C.c_void_p), ("zero_densitys", C.c_void_p), ("velocitys", C.c_void_p),
+                ("smoke_out", C.c_void_p), ("cg_iters", C.c_void_p), ("density_f32", C.c_int32),
+                ("frame_stride", C.c_int32), ("space_stride", C.c_int32)]
+
+
 class ProfileRow(C.Structure):
     """dpc_profile_row (include/dpc.h)."""
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
@@ -70,6 +83,12 @@ _SIGNATURES = {
     "dpc_linear_attention_workspace_bytes": (_Z, [_L, _I]),
     "dpc_linear_attention_core": (C.c_int, [_P, _P, _I, _L, _I, _P, _Z, _P]),
     "dpc_burgers_fd": (C.c_int, [_P, _P, _P, _I, _I, _I, _D, _D, _D, _P]),
+    "dpc_smoke_workspace_bytes": (_Z, [_I, _I]),
+    "dpc_smoke_rollout": (C.c_int, [C.POINTER(SmokeDomain), _P, _L, _P, _P, _P, _I, _I, _I, _I, _D, _D, _I,
+                                    C.POINTER(SmokeOut), _P, _Z, _P]),
+    "dpc_smoke_pressure_solve": (C.c_int, [C.POINTER(SmokeDomain), _P, _I, _D, _I, _P, _P, _Z, _P]),
+    "dpc_smoke_advect": (C.c_int, [_P, _P, _P, _I, _D, _P]),
+    "dpc_smoke_domain_tables": (C.c_int, [C.POINTER(SmokeDomain), _P, _P, _P, _P, _Z, _P]),
 }
 
 

@@ -174,6 +174,55 @@ int dpc_linear_attention_core(const float* qkv, float* out, int heads, int64_t i
 int dpc_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, int num_t, double visc, double T,
                    double dt, dpc_stream_t stream);
 
+
+/* ------------------------------------------------------------------ smoke PDE evaluator (phi rollout)
+ * Replaces dataset/apps/evaluate_solver.py `solver` :205-310 (with `get_envolve` :118-147 and the vendored phi it
+ * drives: FluidSimulation.divergence_free phi/flow.py:318-327, StaggeredGrid.divergence/gradient/advect
+ * phi/math/nd.py:367-427,602-614, SparseCGPressureSolver phi/solver/sparse.py:88-128 + conjugate_gradient
+ * phi/solver/base.py:56-104, SciPyBackend.resample phi/math/scipy_backend.py:58-78).  One persistent workgroup per
+ * trajectory; fp64 with the reference's operation order and numpy's pairwise summation tree => bit-identical output.
+ */
+typedef struct {
+    int32_t n;                  /* cells per side: FluidSimulation([n]*2), evaluate_solver.py:95 (127) */
+    int32_t rim;                /* width of the controlled rim in velocity cells, :132-140 (16) */
+    int32_t n_buckets;          /* :151-152 (7) */
+    int32_t target_bucket;      /* index whose share is the objective, :303 (1) */
+    int32_t bucket_rect[8][4];  /* y, x, len_y, len_x on the padded (n+1)^2 array, :151-152 */
+    const int8_t* fluid_d;      /* [n,n] device, 1 = fluid, 0 = obstacle (FluidSimulation._fluid_mask) */
+    const int8_t* active_d;     /* [n,n] device (FluidSimulation._active_mask) */
+} dpc_smoke_domain;
+
+typedef struct {
+    void* densitys;             /* [B, T', W', W'] or NULL; T' = ceil(num_t/frame_stride), W' = (n+1)/space_stride */
+    void* zero_densitys;        /* same shape or NULL */
+    double* velocitys;          /* [B, T', W', W', 2] or NULL */
+    double* smoke_out;          /* [B, T'] (the reference tiles this scalar over 128 x 128, :307-308) or NULL */
+    int32_t* cg_iters;          /* [B, num_t-1] diagnostic or NULL */
+    int32_t density_f32;        /* 0: densitys/zero_densitys are fp64 (reference dtype), 1: fp32 (same values) */
+    int32_t frame_stride;       /* 1 = every frame (reference); multi_evaluate consumes ::8, inference_2d_smoke.py:389 */
+    int32_t space_stride;       /* 1 = full 128 x 128 (reference); multi_evaluate consumes ::2, :388 */
+} dpc_smoke_out;
+
+size_t dpc_smoke_workspace_bytes(int n, int B);
+
+/* init_velocity f32 [n+1,n+1,2] per trajectory (velocity_batch_stride floats apart; 0 = shared), dens0 f32 [B,nx,nx],
+ * c1/c2 f32 [B,nt,nx,nx]; controls and density are nearest-upsampled x(128/nx) in space and x(num_t/nt) in time as
+ * :221-227 does with np.tile. */
+int dpc_smoke_rollout(const dpc_smoke_domain* dom, const float* init_velocity, int64_t velocity_batch_stride,
+                      const float* dens0, const float* c1, const float* c2, int B, int nx, int nt, int num_t, double dt,
+                      double accuracy, int max_cg_iter, const dpc_smoke_out* out, void* ws, size_t ws_bytes,
+                      dpc_stream_t stream);
+
+/* Operator-level entries (parity tests): masked-Laplacian CG exactly as phi/solver/base.py:56-104 from x0 = 0, in place
+ * on div_to_pressure f64 [B,n,n]; one semi-Lagrangian step; the integer tables derived from the masks
+ * (cf: bits 0-3 = off-diagonals (y-1,x),(y,x-1),(y,x+1),(y+1,x), bits 4-6 = -diagonal; vmask: bit0 x, bit1 y;
+ * bucket: 0 or bucket index + 1). */
+int dpc_smoke_pressure_solve(const dpc_smoke_domain* dom, double* div_to_pressure, int B, double accuracy,
+                             int max_cg_iter, int32_t* iterations, void* ws, size_t ws_bytes, dpc_stream_t stream);
+int dpc_smoke_advect(const double* velocity, const float* density, float* out, int n, double dt, dpc_stream_t stream);
+int dpc_smoke_domain_tables(const dpc_smoke_domain* dom, unsigned char* cf_out, unsigned char* vmask_out,
+                            unsigned char* bucket_out, void* ws, size_t ws_bytes, dpc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
