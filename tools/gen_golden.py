@@ -211,11 +211,7 @@ if __name__ == "__main__":
         SECTIONS.update(gen_golden_burgers.SECTIONS)
     except ImportError:
         pass
-    try:
-        import gen_golden_phi  # noqa: F401
-        SECTIONS.update(gen_golden_phi.SECTIONS)
-    except ImportError:
-        pass
+    # the phi / smoke-evaluator fixtures have their own driver: python tools/gen_golden_phi.py
     want = sys.argv[1:] or list(SECTIONS)
     for s in want:
         print("==", s)

@@ -24,3 +24,136 @@ def gen_burgers_fd():
 
 
 SECTIONS = {"burgers_fd": gen_burgers_fd}
+
+
+# ----------------------------------------------------------------------------- Unet2D (B6)
+def _unet2d_fixture(tag, dim, mults, groups, shape, seed):
+    from gen_golden import save, sd_arrays
+    from model.burgers_1d.unet import Unet2D
+
+    torch.manual_seed(seed)
+    m = Unet2D(dim=dim, init_dim=None, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=groups).eval()
+    with torch.no_grad():                      # make the norm gains/biases matter
+        for n_, p_ in m.named_parameters():
+            if n_.endswith(".g") or n_.endswith("norm.weight") or n_.endswith("norm.bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    x = torch.randn(*shape)
+    t = torch.tensor([3, 977][: shape[0]])
+    taps, hooks = {}, []
+    named = dict(m.named_modules())
+    names = ["init_conv", "time_mlp", "downs.0.0", "downs.0.1", "downs.0.2", "downs.0.3", "mid_block1", "mid_attn",
+             "mid_block2", "ups.0.0", "ups.0.1", "ups.0.2", "ups.0.3", "final_res_block"]
+    last = len(mults) - 1
+    names += [f"downs.{last}.3", f"ups.{last}.3"]
+    for name in names:
+        hooks.append(named[name].register_forward_hook(
+            lambda _m, _i, o, name=name: taps.__setitem__("tap:" + name, o.detach().clone())))
+    with torch.no_grad():
+        y = m(x, t)
+    for h in hooks:
+        h.remove()
+    arrays = dict(x=x, t=t, y=y, dim=dim, dim_mults=np.array(mults), groups=groups)
+    arrays.update(taps)
+    arrays.update(sd_arrays(m))
+    save(f"unet2d_{tag}", **arrays)
+
+
+def gen_unet2d():
+    _unet2d_fixture("a", 8, (1, 2), 1, (2, 2, 16, 32), 0)          # groups = 1 as the scripts launch it
+    _unet2d_fixture("b", 16, (1, 2, 4), 8, (1, 2, 16, 16), 1)      # library default groups = 8, three levels
+
+
+# ----------------------------------------------------------------------------- Burgers sampler (B1-B5)
+def gen_burgers_sampler():
+    from gen_golden import save, sd_arrays
+    from model.burgers_1d.unet import Unet2D
+    from diffusion.diffusion_1d_burgers import (GaussianDiffusion, get_nablaJ, cosine_beta_J_schedule,
+                                                sigmoid_schedule, sigmoid_schedule_flip)
+    from utils import ddpm_guidance_loss, mse_dist_reg
+
+    arrays = {}
+    # B1/B5 tables
+    tt = torch.arange(1000)
+    arrays["sched:J_cosine"] = cosine_beta_J_schedule(tt)
+    arrays["sched:sigmoid"] = sigmoid_schedule(tt)
+    arrays["sched:sigmoid_flip"] = torch.stack([sigmoid_schedule_flip(int(i)) for i in (0, 1, 500, 998, 999)])
+    torch.manual_seed(0)
+    kw = dict(init_dim=None, out_dim=2, channels=2, resnet_block_groups=1)
+    m_uw = Unet2D(dim=8, dim_mults=(1, 2), **kw).eval()
+    m_w = Unet2D(dim=8, dim_mults=(1, 2), **kw).eval()
+    arrays.update(sd_arrays(m_uw, "wuw:"))
+    arrays.update(sd_arrays(m_w, "ww:"))
+    B, Nx, T = 3, 32, 20
+    g = torch.Generator().manual_seed(5)
+    u_target = torch.randn(B, 11, Nx, generator=g)              # un-scaled target trajectories
+    u0 = u_target[:, 0] / 10
+    uT = u_target[:, 10] / 10
+    arrays.update(u_target=u_target)
+    for name in ("betas", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                 "posterior_mean_coef2", "posterior_log_variance_clipped"):
+        pass
+
+    def loss_fn(wu, wf, wreg, po):
+        def f(x):
+            return ddpm_guidance_loss(u_target / 10, x[:, 0, :11, :], x[:, 1, :10, :], wu=wu, wf=wf, wreg=wreg,
+                                      dist_reg=mse_dist_reg, partially_observed=po)
+        return f
+
+    # closed-form gradient check data (B4)
+    xg = torch.randn(B, 2, 16, Nx, generator=g)
+    for tag, (wu, wf, wreg, po) in {"full": (1.5, 0.02, 0.3, None), "po": (2.0, 0.0, 0.1, "front_rear_quarter")}.items():
+        arrays[f"grad:{tag}"] = get_nablaJ(loss_fn(wu, wf, wreg, po))(xg.clone())
+    arrays["grad:x"] = xg
+
+    cases = {
+        # DiffPhyCon POPC recipe (scripts/burgers_inference_partial_obs_partial_ctr.sh) with non-zero guidance weights
+        "popc": dict(two=True, prior_beta=0.9, normalize_beta=False, w_sched="sigmoid_flip", J_sched="cosine",
+                     set_zero=True, cond=True, w=(1.5, 0.02, 0.3, "front_rear_quarter")),
+        # normalised-beta variant, fully observed, no schedulers
+        "norm": dict(two=True, prior_beta=0.7, normalize_beta=True, w_sched=None, J_sched=None, set_zero=False,
+                     cond=True, w=(0.5, 0.01, 0.0, None)),
+        # single model (DiffPhyCon-lite), unconditioned, zero guidance weights as the shipped scripts
+        "lite": dict(two=False, prior_beta=1.0, normalize_beta=False, w_sched=None, J_sched="cosine", set_zero=False,
+                     cond=False, w=(0.0, 0.0, 0.0, None)),
+    }
+    sched_fn = {None: None, "cosine": cosine_beta_J_schedule, "sigmoid_flip": sigmoid_schedule_flip}
+    for tag, c in cases.items():
+        gd = GaussianDiffusion((m_uw, m_w) if c["two"] else m_uw, seq_length=(16, Nx), timesteps=T,
+                               auto_normalize=False, use_conv2d=True, temporal=True, is_condition_u0=c["cond"],
+                               is_condition_uT=c["cond"], set_unobserved_to_zero_during_sampling=c["set_zero"],
+                               eval_two_models=c["two"], prior_beta=c["prior_beta"], normalize_beta=c["normalize_beta"])
+        rec = []
+        orig = gd.p_sample
+
+        def p_sample(x, t, *a, _orig=orig, _rec=rec, **k):
+            xin = x.detach().clone()
+            out = _orig(x, t, *a, **k)
+            _rec.append((t, xin, out[0].detach().clone(), out[1].detach().clone(), out[2].detach().clone()))
+            return out
+
+        gd.p_sample = p_sample
+        torch.manual_seed(31)
+        res = gd.sample(batch_size=B, clip_denoised=True, nablaJ=get_nablaJ(loss_fn(*c["w"])),
+                        J_scheduler=sched_fn[c["J_sched"]], w_scheduler=sched_fn[c["w_sched"]], guidance_u0=True,
+                        u_init=u0, u_final=uT)
+        torch.manual_seed(31)
+        draws = [torch.randn(B, 2, 16, Nx)] + [torch.randn(B, 2, 16, Nx) for _ in range(T - 1)]
+        arrays[f"{tag}:final"] = res.detach()
+        arrays[f"{tag}:noise"] = torch.stack(draws)
+        for (t, xin, xout, x0_, pn) in rec:
+            if t in (19, 10, 1, 0):
+                arrays[f"{tag}:t{t}:x_in"] = xin
+                arrays[f"{tag}:t{t}:x_out"] = xout
+                arrays[f"{tag}:t{t}:x0"] = x0_
+                arrays[f"{tag}:t{t}:pred_noise"] = pn
+                with torch.no_grad():
+                    tb = torch.full((B,), t, dtype=torch.long)
+                    arrays[f"{tag}:t{t}:eps_uw"] = m_uw(xin, tb)
+                    if c["two"]:
+                        xw = xin.clone()
+                        xw[..., 0, 1:10, :] = 0
+                        arrays[f"{tag}:t{t}:eps_w"] = m_w(xw, tb)
+    save("burgers_sampler", **arrays)
+
+
+SECTIONS.update({"unet2d": gen_unet2d, "burgers_sampler": gen_burgers_sampler})

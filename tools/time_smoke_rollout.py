@@ -31,7 +31,7 @@ res = {}
 for name, kw in (("multi_evaluate outputs (::8 frames, ::2 space, f32 density)",
                   dict(frame_stride=8, space_stride=2, density_dtype=torch.float32)),
                  ("reference outputs (all frames, 128^2, f64)", dict())):
-    E.solver_batch(sim, E.init_velocity_(), d0d[:2], c1d[:2], c2d[:2], 4, **kw)          # warm-up / module load
+    E.solver_batch(sim, E.init_velocity_(), d0d[:2], c1d[:2, :2], c2d[:2, :2], 2, **kw)          # warm-up / module load
     torch.cuda.synchronize()
     _lib.profile_begin()
     t0 = time.perf_counter()
