@@ -24,6 +24,22 @@ class Unet3DCfg(C.Structure):
                 ("init_kernel", C.c_int32), ("groups", C.c_int32), ("micro_batch", C.c_int32)]
 
 
+class Unet2DCfg(C.Structure):
+    """dpc_unet2d_cfg (include/dpc.h)."""
+    _fields_ = [("dim", C.c_int32), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 8), ("channels", C.c_int32),
+                ("out_dim", C.c_int32), ("attn_heads", C.c_int32), ("attn_dim_head", C.c_int32), ("groups", C.c_int32),
+                ("micro_batch", C.c_int32)]
+
+
+class BurgersCoef(C.Structure):
+    """dpc_burgers_coef (include/dpc.h)."""
+    _fields_ = [("sqrt_recip_ac", C.c_float), ("sqrt_recipm1_ac", C.c_float), ("mean_coef1", C.c_float),
+                ("mean_coef2", C.c_float), ("sigma", C.c_float), ("w_coef", C.c_float), ("prior_beta", C.c_float),
+                ("eta_J", C.c_float), ("wu", C.c_float), ("wf", C.c_float), ("wreg", C.c_float),
+                ("two_models", C.c_int32), ("normalize_beta", C.c_int32), ("partially_observed", C.c_int32),
+                ("guidance_batch", C.c_int32), ("clip_denoised", C.c_int32), ("cond_idx", C.c_int32)]
+
+
 class SmokeDomain(C.Structure):
     """dpc_smoke_domain (include/dpc.h)."""
     _fields_ = [("n", C.c_int32), ("rim", C.c_int32), ("n_buckets", C.c_int32), ("target_bucket", C.c_int32),
@@ -83,6 +99,17 @@ _SIGNATURES = {
     "dpc_linear_attention_workspace_bytes": (_Z, [_L, _I]),
     "dpc_linear_attention_core": (C.c_int, [_P, _P, _I, _L, _I, _P, _Z, _P]),
     "dpc_burgers_fd": (C.c_int, [_P, _P, _P, _I, _I, _I, _D, _D, _D, _P]),
+    "dpc_unet2d_create": (C.c_int, [C.POINTER(Unet2DCfg), C.POINTER(_P)]),
+    "dpc_unet2d_destroy": (None, [_P]),
+    "dpc_unet2d_load": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(_L), _I, _P]),
+    "dpc_unet2d_set_tables": (C.c_int, [_P, _P, _P]),
+    "dpc_unet2d_finalize": (C.c_int, [_P]),
+    "dpc_unet2d_workspace_bytes": (_Z, [_P, _I, _I, _I]),
+    "dpc_unet2d_forward": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _Z, _P]),
+    "dpc_unet2d_debug_taps": (C.c_int, [_P, _I]),
+    "dpc_unet2d_get_tap": (C.c_int, [_P, C.c_char_p, _P, _Z, _P]),
+    "dpc_burgers_prepare": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dpc_ddpm_update_burgers": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BurgersCoef), _I, _I, _I, _P]),
     "dpc_smoke_workspace_bytes": (_Z, [_I, _I]),
     "dpc_smoke_rollout": (C.c_int, [C.POINTER(SmokeDomain), _P, _L, _P, _P, _P, _I, _I, _I, _I, _D, _D, _I,
                                     C.POINTER(SmokeOut), _P, _Z, _P]),

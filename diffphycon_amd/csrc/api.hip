@@ -28,6 +28,20 @@ int dpc_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w
                                     (hipStream_t)stream);
 }
 
+int dpc_burgers_prepare(float* img, float* x_w, const float* u0, const float* uT, int B, int nt, int nx, int cond_idx,
+                        int set_zero, dpc_stream_t stream) {
+    DPC_REQUIRE(img && B >= 0 && nt >= 2 && nx >= 4 && cond_idx >= 1 && cond_idx < nt, "burgers_prepare: bad argument");
+    return launch_burgers_prepare(img, x_w, u0, uT, B, nt, nx, cond_idx, set_zero, (hipStream_t)stream);
+}
+
+int dpc_ddpm_update_burgers(const float* x, const float* eps_uw, const float* eps_w, const float* z,
+                            const float* u_target, float* x_next, float* x0_out, float* eps_out,
+                            const dpc_burgers_coef* coef, int B, int nt, int nx, dpc_stream_t stream) {
+    DPC_REQUIRE(x && eps_uw && x_next && coef && B >= 0 && nt >= 2 && nx >= 4, "ddpm_update_burgers: bad argument");
+    return launch_ddpm_update_burgers(x, eps_uw, eps_w, z, u_target, x_next, x0_out, eps_out, *coef, B, nt, nx,
+                                      (hipStream_t)stream);
+}
+
 int dpc_philox_normal(float* out, int B, int64_t per_traj, uint64_t seed, int64_t traj0, int64_t draw,
                       dpc_stream_t stream) {
     DPC_REQUIRE(out && B >= 0 && per_traj >= 0, "philox_normal: bad argument");

@@ -145,10 +145,13 @@ struct StemParams {
     long long M;
 };
 int launch_stem(const StemParams& p, hipStream_t s);
-int launch_pack_stem(const float* w, float* wp, int* ktab, int N, int Npad, int C, int k, hipStream_t s);
+int launch_pack_stem(const float* w, float* wp, int* ktab, int N, int Npad, int C, int k, hipStream_t s, int kd = 0);
 
 // ---------------------------------------------------------------- norms (norm.hip)
 int launch_ln_stats(const float* x, float* stats, long long rows, int C, hipStream_t s);
+// out[r][c] = resid[r][c] + (x[r][c] - mean_r) * rstd_r * gamma[c]   (channel LayerNorm + residual; out may alias resid)
+int launch_ln_apply(const float* x, const float* stats, const float* gamma, const float* resid, float* out,
+                    long long rows, int C, hipStream_t s);
 size_t gn_workspace_bytes(int B, int C);
 // out = SiLU(GN(x)*(scale+1)+shift) (+ resid); out may alias x or resid (same-element in-place)
 int launch_groupnorm_silu(const float* x, float* out, const float* resid, const float* gamma, const float* beta,
@@ -177,6 +180,8 @@ int launch_small_linear(const float* in, const float* W, const float* bias, floa
 int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 int launch_cl_to_cf(const float* x_cl, float* x_cf, int BF, int C, long long HW, int F, hipStream_t s);  // debug taps
 int launch_cf_to_cl(const float* x_cf, float* x_cl, int BF, int C, long long HW, hipStream_t s);
+// nearest-neighbour x2 up-sampling of a channels-last image batch [BF][H][W][C] -> [BF][2H][2W][C]
+int launch_upsample2x_cl(const float* x, float* y, int BF, int H, int W, int C, hipStream_t s);
 
 // ---------------------------------------------------------------- sampler update (update.hip)
 int launch_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z,
@@ -184,6 +189,13 @@ int launch_ddpm_update_smoke(const float* x, const float* eps_j, const float* ep
                              const dpc_step_coef& c, int B, int F, int C, int H, int W, hipStream_t s);
 int launch_philox_normal(float* out, int B, long long per_traj, uint64_t seed, long long traj0, long long draw,
                          hipStream_t s);
+
+// Burgers sampler (update.hip)
+int launch_burgers_prepare(float* img, float* x_w, const float* u0, const float* uT, int B, int nt, int nx, int cond_idx,
+                           int set_zero, hipStream_t s);
+int launch_ddpm_update_burgers(const float* x, const float* eps_uw, const float* eps_w, const float* z,
+                               const float* u_target, float* x_next, float* x0_out, float* eps_out,
+                               const dpc_burgers_coef& c, int B, int nt, int nx, hipStream_t s);
 
 // ---------------------------------------------------------------- PDE evaluators
 int launch_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, int num_t, double visc, double T,

@@ -359,8 +359,8 @@ int launch_stem(const StemParams& p, hipStream_t s) {
 }
 
 __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict__ wp, int* __restrict__ ktab, int N,
-                                 int Npad, int C, int k, int kchunks) {
-    const int taps = k * k * k, K = taps * C, pad = k / 2;
+                                 int Npad, int C, int k, int kd, int kchunks) {
+    const int taps = kd * k * k, K = taps * C, pad = k / 2, padd = kd / 2;
     const long long total = (long long)kchunks * Npad * BK;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % BK);
@@ -379,18 +379,19 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, float* __restrict_
             if (kg < K) {
                 const int tap = kg / C, c = kg - tap * C;
                 const int a = tap / (k * k), b = (tap / k) % k, cc = tap % k;
-                e = ((a - pad + 64) << 24) | ((b - pad + 64) << 16) | ((cc - pad + 64) << 8) | c;
+                e = ((a - padd + 64) << 24) | ((b - pad + 64) << 16) | ((cc - pad + 64) << 8) | c;
             }
             ktab[kg] = e;
         }
     }
 }
 
-int launch_pack_stem(const float* w, float* wp, int* ktab, int N, int Npad, int C, int k, hipStream_t s) {
-    const int kchunks = igemm_kchunks(k * k * k * C);
+int launch_pack_stem(const float* w, float* wp, int* ktab, int N, int Npad, int C, int k, hipStream_t s, int kd) {
+    if (kd <= 0) kd = k;                                  // cubic kernel (Unet3D); kd = 1: Conv2d 7x7 (Unet2D)
+    const int kchunks = igemm_kchunks(kd * k * k * C);
     const long long total = (long long)kchunks * Npad * BK;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_stem_kernel, dim3(grid), dim3(256), 0, s, w, wp, ktab, N, Npad, C, k, kchunks);
+    hipLaunchKernelGGL(pack_stem_kernel, dim3(grid), dim3(256), 0, s, w, wp, ktab, N, Npad, C, k, kd, kchunks);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -59,6 +59,37 @@ int launch_ln_stats(const float* x, float* stats, long long rows, int C, hipStre
     return DPC_OK;
 }
 
+// Channel LayerNorm applied from precomputed (mean, rstd) + residual: the trailing LayerNorm of the 2-D LinearAttention
+// (model/burgers_1d/unet.py:59-69, 203-206) followed by Residual (:22-28).
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* resid,
+                                                       float* out, long long rows, int C) {
+    const int c4n = C >> 2;
+    const long long total = rows * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 o = (v - mean) * rstd * g;
+        if (resid) o = o + *reinterpret_cast<const f32x4*>(resid + r * C + c);
+        *reinterpret_cast<f32x4*>(out + r * C + c) = o;
+    }
+}
+
+int launch_ln_apply(const float* x, const float* stats, const float* gamma, const float* resid, float* out,
+                    long long rows, int C, hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0, "ln_apply: C % 4");
+    if (rows == 0) return DPC_OK;
+    ProfScope prof(PROF_LN, 0, 4.0 * (double)rows * C * (resid ? 3 : 2), s);
+    const long long total = rows * (C / 4);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(ln_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, gamma, resid, out, rows, C);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 // ------------------------------------------------------------------ GroupNorm + scale/shift + SiLU
 // Reference: Block.forward (…conv3d.py:196-204) with nn.GroupNorm(groups, C, eps=1e-5).
 constexpr int GN_MAX_CHUNKS = 128;

@@ -97,4 +97,32 @@ int launch_cf_to_cl(const float* x_cf, float* x_cl, int BF, int C, long long HW,
     return DPC_OK;
 }
 
+// nn.Upsample(scale_factor=2, mode='nearest') on channels-last data (model/burgers_1d/unet.py:40-44)
+__global__ __launch_bounds__(256) void upsample2x_cl_kernel(const float* __restrict__ x, float* __restrict__ y, int BF,
+                                                            int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long long total = (long long)BF * 4 * H * W * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        long long r = i / c4n;
+        const int wo = (int)(r % (2 * W));
+        r /= 2 * W;
+        const int ho = (int)(r % (2 * H));
+        const long long bf = r / (2 * H);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((bf * H + (ho >> 1)) * W + (wo >> 1)) * C + c4 * 4);
+        *reinterpret_cast<f32x4*>(y + ((bf * 2 * H + ho) * 2 * W + wo) * C + c4 * 4) = v;
+    }
+}
+
+int launch_upsample2x_cl(const float* x, float* y, int BF, int H, int W, int C, hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0, "upsample2x: C % 4");
+    const long long total = (long long)BF * 4 * H * W * (C / 4);
+    if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_SMALL, 0, 4.0 * (double)BF * H * W * C * 5, s);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(upsample2x_cl_kernel, dim3(grid), dim3(256), 0, s, x, y, BF, H, W, C);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 }  // namespace dpc

@@ -1,0 +1,57 @@
+// Host-side building blocks shared by the two U-Net orchestrators (unet3d.hip, unet2d.hip): owned device buffers,
+// packed GEMM operands and the stack arena that carves the caller's workspace.
+#pragma once
+#include <string>
+
+#include "common.h"
+
+namespace dpc {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        DPC_HIP(hipMalloc(&p, n ? n : 4));
+        return DPC_OK;
+    }
+    float* f() const { return reinterpret_cast<float*>(p); }
+};
+
+struct PackedConv {
+    DevBuf wp;
+    int N = 0, Npad = 0, K = 0, kchunks = 0, ntaps = 0;
+    int sh = 1, sw = 1;
+    bool halo = false;      // 3x3x3 stride-1 conv: packed with bk = 16 for the LDS halo-tile kernel (conv3h.hip)
+    DevBuf wp6;             // ... and pre-split into 3 bf16 planes for the bf16x6 kernel (conv3x6.hip)
+    signed char tdf[32], tdh[32], tdw[32];
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, peak = 0, cap = 0;
+    bool dry = true;
+    bool overflow = false;
+    void* alloc(size_t bytes) {
+        off = align_up(off, 256);
+        void* p = dry ? nullptr : (void*)(base + off);
+        off += bytes;
+        if (off > peak) peak = off;
+        if (!dry && off > cap) overflow = true;
+        return p;
+    }
+    float* allocf(long long n) { return reinterpret_cast<float*>(alloc((size_t)n * sizeof(float))); }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+// Build a PackedConv from a reference-layout conv weight [N][K][kd][kh][kw] / run it (unet3d.hip).
+int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, int kw, int sh, int sw, int pd, int ph,
+                int pw, hipStream_t s);
+int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
+             const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
+             const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s);
+
+}  // namespace dpc

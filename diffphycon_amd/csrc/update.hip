@@ -122,6 +122,123 @@ int launch_ddpm_update_smoke(const float* x, const float* eps_j, const float* ep
     return DPC_OK;
 }
 
+// ------------------------------------------------------------------ Burgers sampler
+// set_condition + zero-fill before every step (diffusion_1d_burgers.py:539-553) and the prior model's input (:399-400)
+__global__ __launch_bounds__(256) void burgers_prepare_kernel(float* __restrict__ img, float* __restrict__ xw,
+                                                              const float* __restrict__ u0, const float* __restrict__ uT,
+                                                              int B, int nt, int nx, int cond_idx, int set_zero) {
+    const long long total = (long long)B * 2 * nt * nx;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % nx);
+        long long r = i / nx;
+        const int row = (int)(r % nt);
+        r /= nt;
+        const int ch = (int)(r % 2);
+        const int b = (int)(r / 2);
+        float v = img[i];
+        if (ch == 0) {
+            if (u0 && row == 0) v = u0[(long long)b * nx + xx];
+            if (uT && row == cond_idx) v = uT[(long long)b * nx + xx];
+            if (set_zero && xx >= nx / 4 && xx < (nx * 3) / 4) v = 0.f;
+            img[i] = v;
+            if (xw) xw[i] = (row >= 1 && row < cond_idx) ? 0.f : v;
+        } else if (xw) {
+            xw[i] = v;
+        }
+    }
+}
+
+int launch_burgers_prepare(float* img, float* x_w, const float* u0, const float* uT, int B, int nt, int nx, int cond_idx,
+                           int set_zero, hipStream_t s) {
+    const long long total = (long long)B * 2 * nt * nx;
+    if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_UPDATE, 0, 4.0 * (double)total * (x_w ? 2.5 : 1.5), s);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(burgers_prepare_kernel, dim3(grid), dim3(256), 0, s, img, x_w, u0, uT, B, nt, nx, cond_idx, set_zero);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// model_predictions (after the denoiser calls) + p_mean_variance + p_sample, one streaming pass:
+//   eps = eps_uw - w_coef*eps_w  (eps_w channel 0 := 0)  | (eps_uw - w_coef*eps_w)/beta          :402-409
+//   x0  = a*x - b*eps                                                                               :426
+//   eps += dJ/dx(x0) * eta_J ; x0 = a*x - b*eps                                                     :431-434
+//   x0.clamp_(-1,1); x' = (m1*x0 + m2*x) + sigma*z                                                  :457-469
+__global__ __launch_bounds__(256) void ddpm_update_burgers_kernel(
+    const float* __restrict__ x, const float* __restrict__ e_uw, const float* __restrict__ e_w,
+    const float* __restrict__ z, const float* __restrict__ ut, float* __restrict__ x_next, float* __restrict__ x0_out,
+    float* __restrict__ eps_out, dpc_burgers_coef k, int B, int nt, int nx) {
+    const long long total = (long long)B * 2 * nt * nx;
+    const float cu = __fdiv_rn(__fmul_rn(2.0f, k.wu), (float)((long long)k.guidance_batch * nx));
+    const float cf = __fdiv_rn(__fmul_rn(2.0f, k.wf), (float)k.guidance_batch);
+    const float cr = __fmul_rn(2.0f, k.wreg);
+    const bool guided = (k.wu != 0.f) || (k.wf != 0.f) || (k.wreg != 0.f);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % nx);
+        long long r = i / nx;
+        const int row = (int)(r % nt);
+        r /= nt;
+        const int ch = (int)(r % 2);
+        const int b = (int)(r / 2);
+        auto mixed_eps = [&](long long j) -> float {
+            float e = e_uw[j];
+            if (k.two_models) {
+                const float w = (ch == 0) ? 0.f : e_w[j];
+                e = __fsub_rn(e, __fmul_rn(k.w_coef, w));
+                if (k.normalize_beta) e = __fdiv_rn(e, k.prior_beta);
+            }
+            return e;
+        };
+        auto x0_at = [&](long long j) -> float {
+            return __fsub_rn(__fmul_rn(k.sqrt_recip_ac, x[j]), __fmul_rn(k.sqrt_recipm1_ac, mixed_eps(j)));
+        };
+        const float xv = x[i];
+        float eps = mixed_eps(i);
+        float x0 = __fsub_rn(__fmul_rn(k.sqrt_recip_ac, xv), __fmul_rn(k.sqrt_recipm1_ac, eps));
+        if (guided) {
+            float g = 0.f;
+            if (ch == 0 && row <= k.cond_idx) {
+                const bool obs = !(k.partially_observed && xx >= nx / 4 && xx < (nx * 3) / 4);
+                if (k.wu != 0.f && obs && (row == 0 || row == k.cond_idx)) {
+                    const float tgt = ut[((long long)b * 2 + (row == 0 ? 0 : 1)) * nx + xx];
+                    g = __fadd_rn(g, __fmul_rn(cu, __fsub_rn(x0, tgt)));
+                }
+                if (k.wreg != 0.f) {
+                    if (row >= 1) g = __fadd_rn(g, __fmul_rn(cr, __fsub_rn(x0, x0_at(i - nx))));
+                    if (row < k.cond_idx) g = __fsub_rn(g, __fmul_rn(cr, __fsub_rn(x0_at(i + nx), x0)));
+                }
+            } else if (ch == 1 && row < k.cond_idx) {
+                g = __fmul_rn(cf, x0);
+            }
+            eps = __fadd_rn(eps, __fmul_rn(g, k.eta_J));
+            x0 = __fsub_rn(__fmul_rn(k.sqrt_recip_ac, xv), __fmul_rn(k.sqrt_recipm1_ac, eps));
+        }
+        if (k.clip_denoised) x0 = clamp1(x0);
+        const float mean = __fadd_rn(__fmul_rn(k.mean_coef1, x0), __fmul_rn(k.mean_coef2, xv));
+        x_next[i] = z ? __fadd_rn(mean, __fmul_rn(k.sigma, z[i])) : mean;
+        if (x0_out) x0_out[i] = x0;
+        if (eps_out) eps_out[i] = eps;
+    }
+}
+
+int launch_ddpm_update_burgers(const float* x, const float* eps_uw, const float* eps_w, const float* z,
+                               const float* u_target, float* x_next, float* x0_out, float* eps_out,
+                               const dpc_burgers_coef& c, int B, int nt, int nx, hipStream_t s) {
+    DPC_REQUIRE(!(c.two_models && !eps_w), "ddpm_update_burgers: two_models needs eps_w");
+    DPC_REQUIRE(!(c.wu != 0.f && !u_target), "ddpm_update_burgers: wu != 0 needs u_target");
+    DPC_REQUIRE(c.cond_idx >= 1 && c.cond_idx < nt, "ddpm_update_burgers: cond_idx");
+    DPC_REQUIRE(c.guidance_batch >= 1, "ddpm_update_burgers: guidance_batch");
+    DPC_REQUIRE(x_next != x || c.wreg == 0.f, "ddpm_update_burgers: in-place update is not allowed with wreg != 0 (row neighbours)");
+    const long long total = (long long)B * 2 * nt * nx;
+    if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_UPDATE, 0, 4.0 * (double)total * (3.5 + (z ? 1 : 0) + (x0_out ? 1 : 0) + (eps_out ? 1 : 0)), s);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(ddpm_update_burgers_kernel, dim3(grid), dim3(256), 0, s, x, eps_uw, eps_w, z, u_target, x_next,
+                       x0_out, eps_out, c, B, nt, nx);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 // ------------------------------------------------------------------ counter-based normal noise
 // Philox4x32-10 keyed by seed; counter = (element/4, draw, trajectory lo, trajectory hi).
 // A trajectory's stream depends only on (seed, global trajectory index, draw): 1-GPU and 8-GPU runs of the

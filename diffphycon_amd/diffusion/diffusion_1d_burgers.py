@@ -1,0 +1,357 @@
+"""Drop-in `GaussianDiffusion` for the 1-D Burgers task: the reference's constructor and `.sample(...)` contract
+(/root/reference/diffusion/diffusion_1d_burgers.py:193-690) driving libdpc.
+
+Per step the hot path is: dpc_burgers_prepare (conditioning rows, zero-fill, prior-model input) -> joint Unet2D forward
+(+ prior Unet2D forward) -> ONE fused guidance + posterior update kernel (dpc_ddpm_update_burgers).  No autograd graph
+and no per-step device sync: the reference's `t[0].item()` scheduler look-ups (:405, :432) become host scalars.
+"""
+import ctypes as C
+import math
+from collections import namedtuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _lib
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+# ----------------------------------------------------------------------------- step-size schedules (:71-127), fp64
+def cosine_beta_J_schedule(t, s=0.008):
+    timesteps = 1000
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    alphas_cumprod = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)[t]
+
+
+def plain_cosine_schedule(t, s=0.0):
+    timesteps = 1000
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    eta = torch.cos((x + s) / (timesteps + s))
+    return eta.flip()[t]          # raises exactly like the reference (:92: flip() without dims)
+
+
+def sigmoid_schedule(t, start=-3, end=3, tau=1, clamp_min=1e-5):
+    timesteps = 1000
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64) / timesteps
+    v_start = torch.tensor(start / tau).sigmoid()
+    v_end = torch.tensor(end / tau).sigmoid()
+    alphas_cumprod = (-((x * (end - start) + start) / tau).sigmoid() + v_end) / (v_end - v_start)
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)[t]
+
+
+def sigmoid_schedule_flip(t):
+    return sigmoid_schedule(999 - t)
+
+
+def linear_beta_schedule(timesteps):
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    steps = timesteps + 1
+    x = torch.linspace(0, timesteps, steps, dtype=torch.float64)
+    alphas_cumprod = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+# ----------------------------------------------------------------------------- guidance
+class BurgersGuidance:
+    """`get_nablaJ(get_loss_fn_2dconv(...))` (inference_1d_burgers.py:129-168, utils.py:1289-1328) in closed form.
+
+    J = wu*mean_{b,x}((u0-u0*)^2 + (uT-uT*)^2 [centre half zeroed if partially observed]) + wf*mean_b sum f^2
+        + wreg*sum (u[t+1]-u[t])^2,   u = x[:,0,:11], f = x[:,1,:10], targets = u_target / RESCALER.
+    Calling it returns dJ/dx like the reference's nablaJ; the sampler reads the weights and evaluates the same
+    expression inside the fused update kernel."""
+
+    def __init__(self, u_target_scaled, wu=0.0, wf=0.0, wreg=0.0, partially_observed=None):
+        if partially_observed not in (None, "front_rear_quarter"):
+            raise ValueError("Unknown partially observed mode")
+        self.u_target = u_target_scaled            # [B, Nt(>=11), Nx], already divided by RESCALER
+        self.wu, self.wf, self.wreg = float(wu), float(wf), float(wreg)
+        self.partially_observed = partially_observed
+
+    def target_rows(self, device):
+        """[B, 2, Nx]: rows t=0 and t=T of the rescaled target (utils.py:1303-1304)."""
+        ut = torch.as_tensor(self.u_target, dtype=torch.float32)
+        return torch.stack((ut[:, 0, :], ut[:, -1, :]), dim=1).to(device).contiguous()
+
+    def __call__(self, x):
+        B, _, _, nx = x.shape
+        g = torch.zeros_like(x)
+        u, f = x[:, 0, :11, :], x[:, 1, :10, :]
+        tr = self.target_rows(x.device)
+        m = torch.ones(nx, device=x.device)
+        if self.partially_observed == "front_rear_quarter":
+            m[nx // 4: (nx * 3) // 4] = 0
+        c = 2.0 * self.wu / (B * nx)
+        g[:, 0, 0, :] += c * (u[:, 0] - tr[:, 0]) * m
+        g[:, 0, 10, :] += c * (u[:, 10] - tr[:, 1]) * m
+        g[:, 1, :10, :] += (2.0 * self.wf / B) * f
+        d = u[:, 1:] - u[:, :-1]
+        g[:, 0, 1:11, :] += 2.0 * self.wreg * d
+        g[:, 0, 0:10, :] -= 2.0 * self.wreg * d
+        return g
+
+
+def get_nablaJ(loss_fn):
+    """Reference signature (:34-49).  On the HIP path the loss must be a `BurgersGuidance` (closed form); arbitrary
+    autograd closures have no kernel."""
+    if isinstance(loss_fn, BurgersGuidance):
+        return loss_fn
+    raise TypeError("get_nablaJ needs a diffphycon_amd BurgersGuidance (closed-form ddpm_guidance_loss); arbitrary "
+                    "autograd closures are not on the HIP path")
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, *, seq_length, timesteps=1000, sampling_timesteps=None, objective="pred_noise",
+                 beta_schedule="cosine", ddim_sampling_eta=0., auto_normalize=True, guidance_u0=True, temporal=False,
+                 use_conv2d=False, is_condition_u0=False, is_condition_uT=False, is_condition_u0_zero_pred_noise=True,
+                 is_condition_uT_zero_pred_noise=True, train_on_partially_observed=None,
+                 set_unobserved_to_zero_during_sampling=False, conditioned_on_residual=None, residual_on_u0=False,
+                 recurrence=False, recurrence_k=1, is_model_w=False, eval_two_models=False, expand_condition=False,
+                 prior_beta=1, normalize_beta=False, train_on_padded_locations=True, condition_idx=10):
+        super().__init__()
+        if not eval_two_models:
+            self.model = model
+            self.channels = self.model.channels
+            self.self_condition = self.model.self_condition
+        else:
+            self.model_uw, self.model_w = model[0], model[1]
+            self.channels = self.model_uw.channels
+            self.self_condition = self.model_uw.self_condition
+        if not (temporal and use_conv2d):
+            raise NotImplementedError("the HIP path implements the 2-D conv (temporal=True, use_conv2d=True) sampler "
+                                      "that get_2d_ddpm builds (train_1d_burgers.py:145-168)")
+        assert type(seq_length) is tuple and len(seq_length) == 2, "should be a tuple of (Nt, Nx)"
+        if auto_normalize or conditioned_on_residual is not None or expand_condition or is_model_w or recurrence:
+            raise NotImplementedError("auto_normalize / residual conditioning / expand_condition / is_model_w / recurrence "
+                                      "are not used by the DiffPhyCon inference scripts")
+        assert objective == "pred_noise", "the Burgers sampler implements pred_noise"
+        self.temporal, self.conv2d, self.traj_size = True, True, seq_length
+        self.objective = objective
+        if beta_schedule == "linear":
+            betas = linear_beta_schedule(timesteps)
+        elif beta_schedule == "cosine":
+            betas = cosine_beta_schedule(timesteps)
+        else:
+            raise ValueError(f"unknown beta schedule {beta_schedule}")
+        alphas = 1. - betas
+        alphas_prev = F.pad(alphas[:-1], (1, 0), value=1.)
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        host = {}
+
+        def register_buffer(name, val):
+            v = val.to(torch.float32)
+            host[name] = v.clone()
+            self.register_buffer(name, v)
+
+        register_buffer("betas", betas)
+        self.alphas = alphas.to(torch.float32).clone()
+        self.alphas_prev = alphas_prev.to(torch.float32).clone()
+        register_buffer("alphas_cumprod", alphas_cumprod)
+        register_buffer("alphas_cumprod_prev", alphas_cumprod_prev)
+        register_buffer("sqrt_alphas_cumprod", torch.sqrt(alphas_cumprod))
+        register_buffer("sqrt_one_minus_alphas_cumprod", torch.sqrt(1. - alphas_cumprod))
+        register_buffer("log_one_minus_alphas_cumprod", torch.log(1. - alphas_cumprod))
+        register_buffer("sqrt_recip_alphas_cumprod", torch.sqrt(1. / alphas_cumprod))
+        register_buffer("sqrt_recipm1_alphas_cumprod", torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        register_buffer("posterior_variance", posterior_variance)
+        register_buffer("posterior_log_variance_clipped", torch.log(posterior_variance.clamp(min=1e-20)))
+        register_buffer("posterior_mean_coef1", betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        register_buffer("posterior_mean_coef2", (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+        snr = alphas_cumprod / (1 - alphas_cumprod)
+        register_buffer("loss_weight", torch.ones_like(snr))
+        self._host = host
+        self._host["sigma"] = (0.5 * host["posterior_log_variance_clipped"]).exp()           # (:469)
+        self.guidance_u0 = guidance_u0
+        self.is_condition_u0, self.is_condition_uT = is_condition_u0, is_condition_uT
+        self.set_unobserved_to_zero_during_sampling = set_unobserved_to_zero_during_sampling
+        self.eval_two_models = eval_two_models
+        self.prior_beta, self.normalize_beta = prior_beta, normalize_beta
+        self.condition_idx = condition_idx
+        self.noise_seed = None          # None -> torch.initial_seed() at sample() time
+        self.traj_offset = 0            # global index of this rank's first trajectory (batch sharding)
+        self.guidance_batch = None      # batch size the guidance loss averages over (None -> local batch)
+        self._draw = 0
+
+    # ------------------------------------------------------------------ noise
+    def sample_noise(self, shape, device):
+        """Counter-based N(0,1) keyed (seed, global trajectory index, draw): sharding-invariant."""
+        out = torch.empty(shape, device=device, dtype=torch.float32)
+        b = shape[0]
+        per = out.numel() // max(b, 1)
+        seed = torch.initial_seed() if self.noise_seed is None else self.noise_seed
+        _lib.check(_lib.lib().dpc_philox_normal(_lib.ptr(out), b, per, seed & (2 ** 64 - 1), self.traj_offset, self._draw,
+                                                _lib.stream()))
+        self._draw += 1
+        return out
+
+    # ------------------------------------------------------------------ per-step pieces
+    def _coef(self, t, guide, J_scheduler, w_scheduler, clip_denoised, batch):
+        h = self._host
+        c = _lib.BurgersCoef()
+        c.sqrt_recip_ac = h["sqrt_recip_alphas_cumprod"][t].item()
+        c.sqrt_recipm1_ac = h["sqrt_recipm1_alphas_cumprod"][t].item()
+        c.mean_coef1 = h["posterior_mean_coef1"][t].item()
+        c.mean_coef2 = h["posterior_mean_coef2"][t].item()
+        c.sigma = h["sigma"][t].item() if t > 0 else 0.0
+        c.two_models = int(self.eval_two_models)
+        c.normalize_beta = int(bool(self.normalize_beta))
+        c.prior_beta = float(self.prior_beta)
+        if self.eval_two_models:
+            eta = float(w_scheduler(t)) if w_scheduler is not None else 1.0                  # (:405)
+            c.w_coef = (1 - self.prior_beta) if self.normalize_beta else (1 - self.prior_beta) * eta
+        c.eta_J = float(J_scheduler(t)) if J_scheduler is not None else 1.0                  # (:432, :495)
+        if guide is not None:
+            c.wu, c.wf, c.wreg = guide.wu, guide.wf, guide.wreg
+            c.partially_observed = int(guide.partially_observed == "front_rear_quarter")
+        c.guidance_batch = int(self.guidance_batch or batch)
+        c.clip_denoised = int(bool(clip_denoised))
+        c.cond_idx = self.condition_idx
+        return c
+
+    def _prepare(self, img, x_w, u0, uT):
+        B, _, nt, nx = img.shape
+        _lib.check(_lib.lib().dpc_burgers_prepare(
+            _lib.ptr(img), _lib.ptr(x_w) if x_w is not None else None, _lib.ptr(u0) if u0 is not None else None,
+            _lib.ptr(uT) if uT is not None else None, B, nt, nx, self.condition_idx,
+            int(self.set_unobserved_to_zero_during_sampling), _lib.stream()))
+
+    def _update(self, x, e_uw, e_w, z, tgt, out, coef, x0_out=None, eps_out=None):
+        B, _, nt, nx = x.shape
+        _lib.check(_lib.lib().dpc_ddpm_update_burgers(
+            _lib.ptr(x), _lib.ptr(e_uw), _lib.ptr(e_w) if e_w is not None else None, _lib.ptr(z) if z is not None else None,
+            _lib.ptr(tgt) if tgt is not None else None, _lib.ptr(out), _lib.ptr(x0_out) if x0_out is not None else None,
+            _lib.ptr(eps_out) if eps_out is not None else None, C.byref(coef), B, nt, nx, _lib.stream()))
+
+    def _denoise(self, img, x_w, t_b):
+        if self.eval_two_models:
+            return self.model_uw(img, t_b), self.model_w(x_w, t_b)
+        return self.model(img, t_b), None
+
+    @staticmethod
+    def _guide(kwargs):
+        nablaJ = kwargs.get("nablaJ")
+        if nablaJ is not None and not isinstance(nablaJ, BurgersGuidance):
+            raise TypeError("nablaJ must be a diffphycon_amd BurgersGuidance (see get_nablaJ)")
+        if kwargs.get("proj_guidance") is not None:
+            raise NotImplementedError("proj_guidance is commented out in the reference's inference script "
+                                      "(inference_1d_burgers.py:379) and has no kernel")
+        return nablaJ
+
+    @torch.no_grad()
+    def p_sample(self, x, t: int, x_self_cond=None, residual=None, **kwargs):
+        """One guided step (:464-470) on an already conditioned x: returns (pred_img, x_start, pred_noise)."""
+        guide = self._guide(kwargs)
+        dev = x.device
+        B = x.shape[0]
+        t_b = torch.full((B,), t, device=dev, dtype=torch.long)
+        x_w = None
+        if self.eval_two_models:                     # x is taken as already conditioned: only build the prior input
+            x_w = torch.empty_like(x)
+            _lib.check(_lib.lib().dpc_burgers_prepare(_lib.ptr(x), _lib.ptr(x_w), None, None, B, x.shape[2], x.shape[3],
+                                                      self.condition_idx, 0, _lib.stream()))
+        e_uw, e_w = self._denoise(x, x_w, t_b)
+        z = self.sample_noise(list(x.shape), dev) if t > 0 else None
+        out, x0, eps = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        tgt = guide.target_rows(dev) if guide is not None and guide.wu != 0 else None
+        coef = self._coef(t, guide, kwargs.get("J_scheduler"), kwargs.get("w_scheduler"), kwargs.get("clip_denoised", True), B)
+        self._update(x, e_uw, e_w, z, tgt, out, coef, x0, eps)
+        return out, x0, eps
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, **kwargs):
+        assert not self.is_ddim_sampling, "wrong branch!"
+        if not self.guidance_u0:
+            raise NotImplementedError("guidance_u0=False (guidance on x_t with a second p_sample) is not used by the scripts")
+        guide = self._guide(kwargs)
+        device = self.betas.device
+        B = shape[0]
+        u0 = kwargs["u_init"].to(device=device, dtype=torch.float32).contiguous() if self.is_condition_u0 else None
+        uT = kwargs["u_final"].to(device=device, dtype=torch.float32).contiguous() if self.is_condition_uT else None
+        tgt = guide.target_rows(device) if guide is not None and guide.wu != 0 else None
+        J_sched, w_sched = kwargs.get("J_scheduler"), kwargs.get("w_scheduler")
+        clip = kwargs.get("clip_denoised", True)
+        img = self.sample_noise(list(shape), device)
+        x_w = torch.empty_like(img) if self.eval_two_models else None
+        pingpong = torch.empty_like(img) if (guide is not None and guide.wreg != 0) else None
+        for t in reversed(range(0, self.num_timesteps)):
+            self._prepare(img, x_w, u0, uT)
+            t_b = torch.full((B,), t, device=device, dtype=torch.long)
+            e_uw, e_w = self._denoise(img, x_w, t_b)
+            z = self.sample_noise(list(shape), device) if t > 0 else None
+            coef = self._coef(t, guide, J_sched, w_sched, clip, B)
+            if pingpong is None:
+                self._update(img, e_uw, e_w, z, tgt, img, coef)
+            else:
+                self._update(img, e_uw, e_w, z, tgt, pingpong, coef)
+                img, pingpong = pingpong, img
+        return img                                  # unnormalize = identity (auto_normalize=False, train_1d_burgers.py:148)
+
+    def ddim_sample(self, shape, return_all_timesteps=False, **kwargs):
+        raise NotImplementedError("Burgers DDIM applies no guidance and rejects the two-model sampler in the reference "
+                                  "(diffusion_1d_burgers.py:616-620); the inference scripts run DDPM (--using_ddim False)")
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, clip_denoised=True, **kwargs):
+        if "guidance_u0" in kwargs:
+            self.guidance_u0 = kwargs["guidance_u0"]
+        if self.is_condition_u0:
+            assert "u_init" in kwargs and kwargs["u_init"] is not None
+        if self.is_condition_uT:
+            assert "u_final" in kwargs and kwargs["u_final"] is not None
+        sample_size = (batch_size, self.channels, *self.traj_size)
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        self._draw = 0
+        return sample_fn(sample_size, clip_denoised=clip_denoised, **kwargs)
+
+
+class Trainer(object):
+    """Checkpoint READER only (training is out of scope): `Trainer(ddpm, dataset, results_folder=...).load(m)` as used
+    by inference_1d_burgers.py:182-206; file name and format of diffusion_1d_burgers.py:934-965
+    (`cos10000-model-{milestone}.pt`, torch.save({'step','model','opt','ema','scaler','version'}))."""
+
+    def __init__(self, diffusion_model, dataset=None, *, results_folder="./results", train_num_steps=100000,
+                 save_and_sample_every=1000, **unused):
+        from pathlib import Path
+        self.model = diffusion_model
+        self.results_folder = Path(results_folder)
+        self.step = 0
+
+    def load(self, milestone):
+        data = torch.load(str(self.results_folder / f"cos10000-model-{milestone}.pt"), map_location="cpu")
+        self.model.load_state_dict(data["model"])
+        self.step = data.get("step", 0)
+
+    def save(self, milestone):
+        self.results_folder.mkdir(exist_ok=True, parents=True)
+        data = {"step": self.step, "model": self.model.state_dict(), "opt": None, "ema": None, "scaler": None}
+        torch.save(data, str(self.results_folder / f"cos10000-model-{milestone}.pt"))

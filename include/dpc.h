@@ -175,6 +175,71 @@ int dpc_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, 
                    double dt, dpc_stream_t stream);
 
 
+/* ------------------------------------------------------------------ Burgers space-time U-Net denoiser
+ * Replaces model/burgers_1d/unet.py Unet2D.__init__ :267-385 (create/load) and .forward :387-431, built by
+ * train/train_1d_burgers.py:get_2d_ddpm :113-143 (channels 2, out_dim 2, attn 4 x 32, sinusoidal time embedding).
+ * Parameter names are the reference's state_dict() keys (e.g. "downs.0.2.fn.fn.to_out.1.g").
+ */
+typedef struct dpc_unet2d_s* dpc_unet2d_t;
+typedef struct {
+    int32_t dim;            /* :274 */
+    int32_t n_mults;        /* len(dim_mults) :277 */
+    int32_t dim_mults[8];
+    int32_t channels;       /* :278 */
+    int32_t out_dim;        /* :276 */
+    int32_t attn_heads;     /* :286 */
+    int32_t attn_dim_head;  /* :285 (only 32) */
+    int32_t groups;         /* resnet_block_groups :280 (scripts: 1) */
+    int32_t micro_batch;    /* trajectories per internal pass (0 = whole batch) */
+} dpc_unet2d_cfg;
+int dpc_unet2d_create(const dpc_unet2d_cfg* cfg, dpc_unet2d_t* out);
+void dpc_unet2d_destroy(dpc_unet2d_t h);
+int dpc_unet2d_load(dpc_unet2d_t h, const char* name, const float* w_d, const int64_t* shape, int ndim,
+                    dpc_stream_t stream);
+/* sin_freqs_d [dim/2] = exp(arange(dim/2) * -log(theta)/(dim/2-1))  (unet.py:93-95) */
+int dpc_unet2d_set_tables(dpc_unet2d_t h, const float* sin_freqs_d, dpc_stream_t stream);
+int dpc_unet2d_finalize(dpc_unet2d_t h);
+size_t dpc_unet2d_workspace_bytes(dpc_unet2d_t h, int B, int H, int W);
+/* x [B,channels,H,W] fp32 (H = padded time rows 16, W = space cells 128), t [B] int64 -> out [B,out_dim,H,W] */
+int dpc_unet2d_forward(dpc_unet2d_t h, const float* x, const int64_t* t, float* out, int B, int H, int W, void* ws,
+                       size_t ws_bytes, dpc_stream_t stream);
+int dpc_unet2d_debug_taps(dpc_unet2d_t h, int enable);
+int dpc_unet2d_get_tap(dpc_unet2d_t h, const char* name, float* dst_d, size_t dst_floats, dpc_stream_t stream);
+
+/* ------------------------------------------------------------------ Burgers guided DDPM update
+ * Replaces diffusion/diffusion_1d_burgers.py: set_condition :500-522 + the zero-fill of p_sample_loop :539-553
+ * (dpc_burgers_prepare, which also builds the prior model's input x_w :399-400), and model_predictions :402-441
+ * (after the denoiser calls) + p_mean_variance :452-461 + p_sample :464-470 (dpc_ddpm_update_burgers), with the
+ * autograd gradient of ddpm_guidance_loss (utils.py:1289-1328; inference_1d_burgers.py:129-165) in closed form.
+ */
+typedef struct {
+    float sqrt_recip_ac;     /* extract(sqrt_recip_alphas_cumprod, t)   :364 */
+    float sqrt_recipm1_ac;   /* extract(sqrt_recipm1_alphas_cumprod, t) :365 */
+    float mean_coef1;        /* posterior_mean_coef1[t] :388 */
+    float mean_coef2;        /* posterior_mean_coef2[t] :389 */
+    float sigma;             /* exp(0.5*posterior_log_variance_clipped[t]) :469 (ignored when z == NULL) */
+    float w_coef;            /* two models: (1-prior_beta)*eta_w(t) :409, or (1-prior_beta) when normalize_beta :407 */
+    float prior_beta;        /* divisor of the normalize_beta branch :407 */
+    float eta_J;             /* nablaJ_scheduler(t) :432 */
+    float wu, wf, wreg;      /* guidance weights of ddpm_guidance_loss */
+    int32_t two_models;      /* eval_two_models :397 */
+    int32_t normalize_beta;  /* :406 */
+    int32_t partially_observed; /* 1 = 'front_rear_quarter': centre half of loss_u zeroed, utils.py:1311-1314 */
+    int32_t guidance_batch;  /* batch size the reference averages the loss over (the whole sample() batch) */
+    int32_t clip_denoised;   /* :457 */
+    int32_t cond_idx;        /* condition_idx :224 (10): last physical time row */
+} dpc_burgers_coef;
+
+/* img [B,2,nt,nx] in place: img[:,0,0,:] = u0, img[:,0,cond_idx,:] = uT (NULL = skip), centre half of channel 0 zeroed
+ * when set_zero; x_w (NULL = skip) receives a copy with rows 1..cond_idx-1 of channel 0 zeroed. */
+int dpc_burgers_prepare(float* img, float* x_w, const float* u0, const float* uT, int B, int nt, int nx, int cond_idx,
+                        int set_zero, dpc_stream_t stream);
+/* x, eps_uw, eps_w, z, x_next, x0_out, eps_out: [B,2,nt,nx]; u_target [B,2,nx] = rescaled target rows (t=0, t=T) or
+ * NULL when wu == 0.  eps_w may be NULL when !two_models; z NULL = no noise (t == 0).  x_next may alias x. */
+int dpc_ddpm_update_burgers(const float* x, const float* eps_uw, const float* eps_w, const float* z,
+                            const float* u_target, float* x_next, float* x0_out, float* eps_out,
+                            const dpc_burgers_coef* coef, int B, int nt, int nx, dpc_stream_t stream);
+
 /* ------------------------------------------------------------------ smoke PDE evaluator (phi rollout)
  * Replaces dataset/apps/evaluate_solver.py `solver` :205-310 (with `get_envolve` :118-147 and the vendored phi it
  * drives: FluidSimulation.divergence_free phi/flow.py:318-327, StaggeredGrid.divergence/gradient/advect
