@@ -106,8 +106,137 @@ def cpu_baseline(sd_cpu, init1):
                       f"threads: {dt:.2f} s/step, extrapolated x1000 steps"}
 
 
+def burgers_setup(device, batch, rank):
+    """BASELINE.json configs[1]: Burgers POPC recipe of scripts/burgers_inference_partial_obs_partial_ctr.sh."""
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from diffphycon_amd.diffusion import diffusion_1d_burgers as D
+    torch.manual_seed(0)
+    kw = dict(dim=64, out_dim=2, channels=2, resnet_block_groups=1)
+    m_uw = Unet2D(dim_mults=(1, 2, 4, 8, 16), **kw)
+    m_w = Unet2D(dim_mults=(1, 2, 4, 8), **kw)
+    sd_cpu = tuple({k: v.clone() for k, v in m.state_dict().items()} for m in (m_uw, m_w))
+    gd = D.GaussianDiffusion((m_uw.to(device), m_w.to(device)), seq_length=(16, 128), timesteps=1000, auto_normalize=False,
+                             use_conv2d=True, temporal=True, is_condition_u0=True, is_condition_uT=True,
+                             set_unobserved_to_zero_during_sampling=True, eval_two_models=True, prior_beta=0.9,
+                             normalize_beta=False).to(device)
+    # SURVEY.md 8(d): u0 = two Gaussians (generate_burgers.py:361-372), uT = u0 rolled by 16 cells, both / 10
+    g = torch.Generator().manual_seed(1000 + rank)
+    xg = torch.linspace(0, 1, 128)[None, :]
+    def bump(lo, hi, alo, ahi):
+        loc = lo + (hi - lo) * torch.rand(batch, 1, generator=g)
+        amp = alo + (ahi - alo) * torch.rand(batch, 1, generator=g)
+        sig = 0.05 + 0.10 * torch.rand(batch, 1, generator=g)
+        return amp * torch.exp(-0.5 * ((xg - loc) / sig) ** 2)
+    u0 = bump(0.2, 0.4, 0.0, 2.0) + bump(0.6, 0.8, -2.0, 0.0)
+    uT = torch.roll(u0, 16, dims=1)
+    ut = torch.zeros(batch, 11, 128)
+    ut[:, 0], ut[:, 10] = u0, uT
+    guide = D.BurgersGuidance(ut / 10, 0.0, 0.0, 0.0, "front_rear_quarter")       # shipped scripts: all-zero weights
+    kwargs = dict(nablaJ=guide, J_scheduler=D.cosine_beta_J_schedule, w_scheduler=D.sigmoid_schedule_flip,
+                  u_init=(u0 / 10).to(device), u_final=(uT / 10).to(device), clip_denoised=True)
+    return gd, kwargs, sd_cpu, (u0 / 10, uT / 10)
+
+
+def burgers_cpu_baseline(sd_cpu, cond):
+    """One guided DDPM step of the POPC recipe at B=8 on the CPU oracle (torch fp32, all usable cores)."""
+    from oracle import unet2d as U
+    from oracle import sampler_burgers as S
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    B = 8
+    c_uw = U.Unet2DConfig(dim=64, dim_mults=(1, 2, 4, 8, 16), resnet_block_groups=1)
+    c_w = U.Unet2DConfig(dim=64, dim_mults=(1, 2, 4, 8), resnet_block_groups=1)
+    sched = S.make_schedule(1000, "cosine")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 2, 16, 128, generator=g)
+    z = torch.randn(B, 2, 16, 128, generator=g)
+    tb = torch.full((B,), 999, dtype=torch.long)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        S.set_conditions(x, cond[0][:B], cond[1][:B], True)
+        e_uw = U.unet2d_forward(sd_cpu[0], c_uw, x, tb)
+        e_w = U.unet2d_forward(sd_cpu[1], c_w, S.w_model_input(x), tb)
+        S.p_sample_step(sched, x, 999, e_uw, e_w, z, prior_beta=0.9, eta_w=S.scheduler_table("sigmoid_flip")[999],
+                        eta_J=S.scheduler_table("cosine")[999])
+    dt = time.perf_counter() - t0
+    return {"value": B / (STEPS_PER_TRAJECTORY * dt), "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"1 guided DDPM step (joint+prior Unet2D forward + update) at B={B}, 16x128, torch fp32 on {cores} "
+                      f"threads: {dt:.2f} s/step, extrapolated x1000 steps"}
+
+
+def main_burgers(args, rank, world, device, dist):
+    """`--workload burgers`: Burgers POPC, 1000-step DDPM, batch 256 per GPU (BASELINE.json configs[1])."""
+    from diffphycon_amd import _lib
+    B = args.batch if args.batch != LOCAL_BATCH else 256
+    gd, kwargs, sd_cpu, cond = burgers_setup(device, B, rank)
+    gd.noise_seed, gd.traj_offset, gd.guidance_batch = 0, rank * B, B
+    guide = kwargs["nablaJ"]
+    img = gd.sample_noise([B, 2, 16, 128], device)
+    x_w = torch.empty_like(img)
+
+    def step(t):
+        gd._prepare(img, x_w, kwargs["u_init"], kwargs["u_final"])
+        t_b = torch.full((B,), t, device=device, dtype=torch.long)
+        e_uw, e_w = gd._denoise(img, x_w, t_b)
+        z = gd.sample_noise([B, 2, 16, 128], device)
+        gd._update(img, e_uw, e_w, z, None, img, gd._coef(t, guide, kwargs["J_scheduler"], kwargs["w_scheduler"], True, B))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t_cur = 999
+    for _ in range(args.warmup):
+        step(t_cur)
+        t_cur -= 1
+        sync()
+    _lib.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(t_cur)
+        t_cur -= 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_end()
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(img).all()
+    if rank == 0:
+        sec = elapsed / args.steps
+        name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["flops"] > 0 else d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
+        roof = ({"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS} if d["flops"] > 0 else
+                {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0})
+        roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": d["launches"],
+                     "avg_launch_ms": d["total_ms"] / max(d["launches"], 1),
+                     "breakdown_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+                     "kernel_time_fraction_of_step": sum(v["total_ms"] for v in prof.values()) / (elapsed * 1e3),
+                     "step_flops_fraction_of_fp32_peak": (B * 15.8 / 1e3 / sec) / PEAK_FP32_MFMA_TFLOPS})
+        out = {"metric": "guided trajectories/sec, 1D Burgers POPC 128 cells x 10 steps @1000 DDPM steps",
+               "value": world * B / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "Burgers POPC (BASELINE.json configs[1]): 128 cells x 10 steps (16x128 padded), "
+                                      f"1000-step guided DDPM, batch={B} per GPU; one step = prepare + joint Unet2D(dim 64, "
+                                      "mults 1-2-4-8-16) + prior Unet2D(1-2-4-8) + fused update",
+                          "global_batch": world * B, "parallelism": f"batch-shard x{world}"},
+               "roofline": roof,
+               "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else burgers_cpu_baseline(sd_cpu, cond)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers"],
+                    help="smoke = BASELINE.json's headline metric (default); burgers = configs[1]")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -130,6 +259,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
 
+    if args.workload == "burgers":
+        return main_burgers(args, rank, world, device, dist)
     from diffphycon_amd import _lib
     from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
     gd, sd_cpu = build_models(device, args.micro_batch)

@@ -1,0 +1,212 @@
+"""2-D smoke control inference with the reference's entry surface (inference/inference_2d_smoke.py): same flags,
+same `load_ddpm_model / load_model / InferencePipeline.{run_model, multi_evaluate, run} / inference / load_data / main`
+structure, running on libdpc (HIP) through the `diffphycon_amd` mirrors.
+
+Differences from the reference, all host-side:
+  * `guidance_fn` is the closed-form `SmokeGuidance` (same gradient; evaluated inside the fused update kernel);
+  * `multi_evaluate` runs all trajectories of a batch in ONE GPU launch (`solver_batch`) instead of one CPU process per
+    trajectory, and keeps only the sub-sampled frames the metrics read (:388-390);
+  * `--synthetic True` (extra flag) fabricates the test split and random-initialises the two U-Nets when no dataset /
+    checkpoint is mounted; one process per GPU shards the batches (torchrun), metrics are gathered with RCCL.
+"""
+import argparse
+import datetime
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from diffphycon_amd.dataset.data_2d import Smoke, SyntheticSmoke  # noqa: E402
+from diffphycon_amd.dataset.apps.evaluate_solver import init_sim_128, init_velocity_, solver_batch  # noqa: E402
+from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, SmokeGuidance, Trainer  # noqa: E402
+from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D  # noqa: E402
+from diffphycon_amd import parallel  # noqa: E402
+from filepath import SMOKE_DATA_PATH, SMOKE_RESULTS_PATH  # noqa: E402
+
+
+def guidance_fn(x, args, RESCALER, w_energy=0, w_init=0, low=None, init=None, init_u=None):
+    """dJ/d(x*RESCALER) of the reference's objective (:30-44), closed form."""
+    return SmokeGuidance(RESCALER.reshape(-1), w_energy, w_init)(x)
+
+
+def _ddpm(model, args, eval_2ddpm=False, **kw):
+    return GaussianDiffusion(
+        model, image_size=args.image_size, frames=32, timesteps=1000,
+        sampling_timesteps=args.ddim_sampling_steps if args.using_ddim else 1000, ddim_sampling_eta=args.ddim_eta,
+        loss_type="l2", objective="pred_noise", standard_fixed_ratio=args.standard_fixed_ratio,
+        coeff_ratio=args.coeff_ratio, eval_2ddpm=eval_2ddpm, **kw)
+
+
+def load_ddpm_model(args, RESCALER):
+    model_joint = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6).to(args.device)
+    diffusion_joint = _ddpm(model_joint, args)
+    model_w = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=2).to(args.device)
+    diffusion_w = _ddpm(model_w, args)
+    if not args.synthetic:
+        Trainer(diffusion_joint, dataset=args.dataset, dataset_path=args.dataset_path,
+                results_path=args.diffusion_model_joint_path, amp=False).load(args.diffusion_joint_checkpoint)
+        Trainer(diffusion_w, dataset=args.dataset, dataset_path=args.dataset_path,
+                results_path=args.diffusion_model_w_path, amp=False).load(args.diffusion_w_checkpoint)
+    diffusion = _ddpm([diffusion_joint.model, diffusion_w.model], args, eval_2ddpm=True, w_prob_exp=args.w_prob_exp,
+                      device=args.device)
+    return diffusion, args.device
+
+
+def load_model(args, RESCALER, w_energy=0, w_init=0):
+    if args.inference_method != "DDPM":
+        raise NotImplementedError("only --inference_method DDPM is implemented by the reference script as well")
+    diffusion, device = load_ddpm_model(args, RESCALER)
+    design_fn = SmokeGuidance(RESCALER.reshape(-1).float(), w_energy, w_init)
+    return [diffusion], design_fn
+
+
+class InferencePipeline(object):
+    def __init__(self, model, args=None, RESCALER=1, results_path=None, args_general=None):
+        self.model, self.args, self.results_path, self.args_general = model, args, results_path, args_general
+        self.image_size, self.device, self.upsample = args_general.image_size, args_general.device, args_general.upsample
+        self.RESCALER = RESCALER
+        self.sim = init_sim_128()
+        os.makedirs(self.results_path, exist_ok=True)
+
+    def run_model(self, state):
+        """state: not rescaled [B, 256, 6, 64, 64] -> sampled + rescaled [B, 32, 6, 64, 64]   (:179-197)"""
+        state = state.to(self.args_general.device)[:, ::8]
+        output = self.model[0].sample(
+            batch_size=state.shape[0], design_fn=self.args["design_fn"], design_guidance=self.args["design_guidance"],
+            low=None, init=state[:, 0, 0] / self.RESCALER[:, 0, 0], init_u=state[:, 0, 0],
+            control=state[:, :, 3:5] / self.RESCALER[:, :, 3:5])
+        output = output * self.RESCALER
+        output[:, :, -1] = output[:, :, -1].mean((-2, -1)).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 64, 64)
+        return output
+
+    def multi_evaluate(self, pred, data, plot=False, method="DDPM"):
+        """pred [B,32,6,64,64], data [B,256,6,64,64]: roll the sampled controls through the PDE solver and score
+        (:317-427).  Returns per-batch means (J_total, J_target, J_energy, mse, n_l2) as arrays of length 1."""
+        k = int(data.shape[-1] / pred.shape[-1])
+        data = data.to(pred.device)
+        pred[:, 0, 0] = data[:, 0, 0, ::k, ::k]
+        start = time.time()
+        pred_ = pred.detach().clone()
+        pred_[:, :, 3:5, 8:56, 8:56] = 0                                         # indirect control (:330)
+        dens, _, vel, smoke = solver_batch(self.sim, init_velocity_(), data[:, 0, 0], pred_[:, :, 3], pred_[:, :, 4],
+                                           per_timelength=256, frame_stride=8, space_stride=2, want_zero_density=False)
+        B = pred.shape[0]
+        cur = torch.empty(B, 32, 6, 64, 64, dtype=torch.float64, device=pred.device)     # data_current (:388-390)
+        cur[:, :, 0] = dens
+        cur[:, :, 1], cur[:, :, 2] = vel[..., 0], vel[..., 1]
+        cur[:, :, 3], cur[:, :, 4] = pred_[:, :, 3].double(), pred_[:, :, 4].double()
+        cur[:, :, 5] = smoke[:, :, None, None]
+        print(f"Time cost: {time.time() - start}")
+        mask = torch.ones_like(pred)
+        mask[:, 0] = 0
+        p, d = pred * mask, cur * mask
+        diff = p - d
+        mse = torch.cat((diff[:, :, :3], diff[:, :, [-1]]), dim=2).square().mean((1, 2, 3, 4))
+        n_l2 = diff[:, :, :3].square().sum((1, 2, 3, 4)).sqrt() / d[:, :, :3].square().sum((1, 2, 3, 4)).sqrt()
+        J_target = -d[:, -1, -1, 0, 0]
+        J_energy = d[:, :, 3:5].square().mean((1, 2, 3, 4))
+        J_total = J_target + self.args_general.w_energy * J_energy
+        rows = torch.stack((J_total, J_target, J_energy, mse, n_l2), dim=1)          # [B, 5] metric rows
+        rows = parallel.gather_metric_rows(rows)                                      # RCCL all_gather when sharded
+        m = rows.mean(0).cpu().numpy()
+        print("J_total=J_target+w*J_energy=", m[1], "+", self.args_general.w_energy, "*", m[2], "=", m[0])
+        print("mse=", m[3], "normalized_l2=", m[4])
+        return tuple(np.array([v]) for v in m)
+
+    def run(self, dataloader):
+        J = {k: [] for k in ("J_total", "J_target", "J_energy", "mse", "n_l2")}
+        for i, (state, sim_id) in enumerate(dataloader):
+            print(f"Batch No.{i}")
+            pred = self.run_model(state)
+            print("pred shape: ", pred.shape)
+            out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
+            for key, v in zip(J, out):
+                J[key].append(v)
+        summary = ",\n".join(f"{k}: {np.stack(v).mean(0)}" for k, v in J.items())
+        print("Final results!\nNumber of upsampling times: 0\n" + summary)
+        with open(os.path.join(self.results_path, "results.txt"), "a") as f:
+            f.write(datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S") + "\n" + str(self.args_general) + "\n")
+            f.write("Number of upsampling times: 0\n" + summary + "\n" + "-" * 89 + "\n")
+        return {k: np.stack(v).mean(0) for k, v in J.items()}
+
+
+def inference(dataloader, diffusion, design_fn, args, RESCALER):
+    ppl = InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": args.design_guidance}, RESCALER,
+                            results_path=args.inference_result_subpath, args_general=args)
+    return ppl.run(dataloader)
+
+
+def load_data(args):
+    assert args.dataset == "Smoke"
+    if args.synthetic:
+        dataset = SyntheticSmoke(n_simu=args.n_test, size=args.image_size)
+    else:
+        dataset = Smoke(dataset_path=args.dataset_path, is_train=False)
+    RESCALER = dataset.RESCALER.unsqueeze(0).to(args.device)
+    # batch-shard the test split over ranks (one process per GPU); a rank's trajectories keep their global index
+    start, stop = parallel.shard_range(len(dataset), args.rank, args.world_size)
+    subset = torch.utils.data.Subset(dataset, range(start, stop))
+    loader = torch.utils.data.DataLoader(subset, batch_size=args.batch_size, shuffle=False, pin_memory=True,
+                                         num_workers=0 if args.synthetic else 8)
+    print("number of batch in test_loader: ", len(loader))
+    return loader, RESCALER
+
+
+def main(args):
+    dataloader, RESCALER = load_data(args)
+    diffusion, design_fn = load_model(args, RESCALER, args.w_energy, w_init=args.w_init)
+    diffusion[0].traj_offset = parallel.shard_range(args.n_test if args.synthetic else 50, args.rank, args.world_size)[0]
+    return inference(dataloader, diffusion, design_fn, args, RESCALER)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="inference 2d inverse design model")
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--dataset", default="Smoke", type=str)
+    parser.add_argument("--dataset_path", default=SMOKE_DATA_PATH, type=str)
+    parser.add_argument("--w_energy", default=0, type=float)
+    parser.add_argument("--image_size", type=int, default=64)
+    parser.add_argument("--upsample", default=0, type=int)
+    parser.add_argument("--is_condition_pad", default=True, type=eval)
+    parser.add_argument("--is_condition_reward", default=False, type=eval)
+    parser.add_argument("--batch_size", default=50, type=int)
+    parser.add_argument("--inference_result_path", default=os.path.join(SMOKE_RESULTS_PATH, "inference_results"), type=str)
+    parser.add_argument("--inference_method", default="DDPM", type=str)
+    parser.add_argument("--diffusion_model_joint_path", default=os.path.join(SMOKE_RESULTS_PATH, "checkpoints/joint_models"), type=str)
+    parser.add_argument("--diffusion_joint_checkpoint", default=50, type=int)
+    parser.add_argument("--diffusion_model_w_path", default=os.path.join(SMOKE_RESULTS_PATH, "checkpoints/w_models"), type=str)
+    parser.add_argument("--diffusion_w_checkpoint", default=17, type=int)
+    parser.add_argument("--using_ddim", default=True, type=eval)
+    parser.add_argument("--ddim_eta", default=1., type=float)
+    parser.add_argument("--w_prob_exp", default=0.97, type=float)
+    parser.add_argument("--ddim_sampling_steps", default=100, type=int)
+    parser.add_argument("--design_guidance", default="standard", type=str)
+    parser.add_argument("--standard_fixed_ratio", default=100000, type=float)
+    parser.add_argument("--coeff_ratio", default=0, type=float)
+    parser.add_argument("--w_init", default=0, type=float)
+    # extra (not in the reference): run without datasets / checkpoints
+    parser.add_argument("--synthetic", default=False, type=eval, help="synthetic test split + random-init U-Nets")
+    parser.add_argument("--n_test", default=50, type=int, help="synthetic test-set size")
+    return parser
+
+
+if __name__ == "__main__":
+    args = build_parser().parse_args()
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    assert torch.cuda.is_available(), "the HIP path needs a GPU"
+    args.rank, args.world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    args.device = torch.device("cuda", local)
+    if args.world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size, device_id=args.device)
+    args.inference_result_subpath = os.path.join(args.inference_result_path,
+                                                 datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
+    print("args: ", args)
+    main(args)
