@@ -40,6 +40,12 @@ class BurgersCoef(C.Structure):
                 ("guidance_batch", C.c_int32), ("clip_denoised", C.c_int32), ("cond_idx", C.c_int32)]
 
 
+class JellyCoef(C.Structure):
+    """dpc_jelly_coef (include/dpc.h)."""
+    _fields_ = [("sqrt_recip_ac", C.c_float), ("sqrt_recipm1_ac", C.c_float), ("mean_coef1", C.c_float),
+                ("mean_coef2", C.c_float), ("sigma", C.c_float), ("clip_denoised", C.c_int32), ("mode", C.c_int32)]
+
+
 class SmokeDomain(C.Structure):
     """dpc_smoke_domain (include/dpc.h)."""
     _fields_ = [("n", C.c_int32), ("rim", C.c_int32), ("n_buckets", C.c_int32), ("target_bucket", C.c_int32),
@@ -110,6 +116,8 @@ _SIGNATURES = {
     "dpc_unet2d_get_tap": (C.c_int, [_P, C.c_char_p, _P, _Z, _P]),
     "dpc_burgers_prepare": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpc_ddpm_update_burgers": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BurgersCoef), _I, _I, _I, _P]),
+    "dpc_ddpm_update_jelly": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(JellyCoef), _I, _I, _I, _I, _I, _I, _P]),
+    "dpc_jelly_apply_guidance": (C.c_int, [_P, _P, _P, C.c_float, C.c_float, _I, C.c_float, _I, _I, _I, _I, _I, _P]),
     "dpc_smoke_workspace_bytes": (_Z, [_I, _I]),
     "dpc_smoke_rollout": (C.c_int, [C.POINTER(SmokeDomain), _P, _L, _P, _P, _P, _I, _I, _I, _I, _D, _D, _I,
                                     C.POINTER(SmokeOut), _P, _Z, _P]),

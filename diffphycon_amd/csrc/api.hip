@@ -42,6 +42,19 @@ int dpc_ddpm_update_burgers(const float* x, const float* eps_uw, const float* ep
                                       (hipStream_t)stream);
 }
 
+int dpc_ddpm_update_jelly(const float* x, const float* eps, const float* eps_guided, const float* z, float* pred,
+                          float* x0_out, const dpc_jelly_coef* coef, int B, int F, int Cx, int n_state, int H, int W,
+                          dpc_stream_t stream) {
+    DPC_REQUIRE(x && eps && pred && coef && B >= 0 && F >= 1 && H >= 1 && W >= 1, "ddpm_update_jelly: bad argument");
+    return launch_ddpm_update_jelly(x, eps, eps_guided, z, pred, x0_out, *coef, B, F, Cx, n_state, H, W, (hipStream_t)stream);
+}
+
+int dpc_jelly_apply_guidance(float* io, const float* g, const float* eps_w, float eta_J, float eta_w, int pad_w,
+                             float sign, int B, int F, int Cd, int H, int W, dpc_stream_t stream) {
+    DPC_REQUIRE(io && B >= 0 && F >= 1 && Cd >= 1 && H >= 1 && W >= 1, "jelly_apply_guidance: bad argument");
+    return launch_jelly_guidance(io, g, eps_w, eta_J, eta_w, pad_w, sign, B, F, Cd, H, W, (hipStream_t)stream);
+}
+
 int dpc_philox_normal(float* out, int B, int64_t per_traj, uint64_t seed, int64_t traj0, int64_t draw,
                       dpc_stream_t stream) {
     DPC_REQUIRE(out && B >= 0 && per_traj >= 0, "philox_normal: bad argument");

@@ -197,6 +197,12 @@ int launch_ddpm_update_burgers(const float* x, const float* eps_uw, const float*
                                const float* u_target, float* x_next, float* x0_out, float* eps_out,
                                const dpc_burgers_coef& c, int B, int nt, int nx, hipStream_t s);
 
+int launch_ddpm_update_jelly(const float* x, const float* eps, const float* eps_g, const float* z, float* pred,
+                             float* x0_out, const dpc_jelly_coef& c, int B, int F, int Cx, int ns, int H, int W,
+                             hipStream_t s);
+int launch_jelly_guidance(float* io, const float* g, const float* eps_w, float eta_J, float eta_w, int pad_w, float sign,
+                          int B, int F, int Cd, int H, int W, hipStream_t s);
+
 // ---------------------------------------------------------------- PDE evaluators
 int launch_burgers_fd(const float* u0, const float* f, float* traj, int N, int nx, int num_t, double visc, double T,
                       double dt, hipStream_t s);

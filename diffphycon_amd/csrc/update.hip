@@ -239,6 +239,80 @@ int launch_ddpm_update_burgers(const float* x, const float* eps_uw, const float*
     return DPC_OK;
 }
 
+// ------------------------------------------------------------------ jellyfish sampler
+__global__ __launch_bounds__(256) void ddpm_update_jelly_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                                const float* __restrict__ eps_g, const float* __restrict__ z,
+                                                                float* __restrict__ pred, float* __restrict__ x0_out,
+                                                                dpc_jelly_coef k, int B, int F, int Cx, int ns, long long HW) {
+    const int Cd = ns + 1;
+    const long long total = (long long)B * F * Cd * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        long long r = i / HW;
+        const int c = (int)(r % Cd);
+        const long long bf = r / Cd;
+        const int cx = (c < ns) ? c : Cx - 1;
+        const float xv = x[(bf * Cx + cx) * HW + hw];
+        float x0 = __fsub_rn(__fmul_rn(k.sqrt_recip_ac, xv), __fmul_rn(k.sqrt_recipm1_ac, eps[i]));
+        float out;
+        if (k.mode == 0) {
+            if (k.clip_denoised) x0 = clamp1(x0);
+            const float mean = __fadd_rn(__fmul_rn(k.mean_coef1, x0), __fmul_rn(k.mean_coef2, xv));
+            out = z ? __fadd_rn(mean, __fmul_rn(k.sigma, z[i])) : mean;
+        } else if (k.mode == 1) {
+            const float e = eps_g ? eps_g[i] : eps[i];
+            out = __fadd_rn(__fmul_rn(x0, k.mean_coef1), __fmul_rn(k.mean_coef2, e));
+            if (z) out = __fadd_rn(out, __fmul_rn(k.sigma, z[i]));
+        } else {
+            out = x0;
+        }
+        pred[i] = out;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+__global__ __launch_bounds__(256) void jelly_guidance_kernel(float* __restrict__ io, const float* __restrict__ g,
+                                                             const float* __restrict__ eps_w, float eta_J, float eta_w,
+                                                             int pad_w, float sign, long long BF, int Cd, long long HW) {
+    const long long total = BF * Cd * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        long long r = i / HW;
+        const int c = (int)(r % Cd);
+        const long long bf = r / Cd;
+        float w = 0.f;
+        if (eps_w && (!pad_w || c == Cd - 1)) w = eps_w[bf * HW + hw];
+        const float gf = __fsub_rn(__fmul_rn(eta_J, g ? g[i] : 0.f), __fmul_rn(eta_w, w));
+        io[i] = (sign < 0.f) ? __fsub_rn(io[i], gf) : __fadd_rn(io[i], gf);
+    }
+}
+
+int launch_ddpm_update_jelly(const float* x, const float* eps, const float* eps_g, const float* z, float* pred,
+                             float* x0_out, const dpc_jelly_coef& c, int B, int F, int Cx, int ns, int H, int W,
+                             hipStream_t s) {
+    DPC_REQUIRE(ns >= 1 && ns < Cx && c.mode >= 0 && c.mode <= 2, "ddpm_update_jelly: bad channel split / mode");
+    const long long total = (long long)B * F * (ns + 1) * H * W;
+    if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_UPDATE, 0, 4.0 * (double)total * (3 + (z ? 1 : 0) + (x0_out ? 1 : 0) + (eps_g ? 1 : 0)), s);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(ddpm_update_jelly_kernel, dim3(grid), dim3(256), 0, s, x, eps, eps_g, z, pred, x0_out, c, B, F, Cx, ns,
+                       (long long)H * W);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int launch_jelly_guidance(float* io, const float* g, const float* eps_w, float eta_J, float eta_w, int pad_w, float sign,
+                          int B, int F, int Cd, int H, int W, hipStream_t s) {
+    const long long total = (long long)B * F * Cd * H * W;
+    if (total == 0) return DPC_OK;
+    ProfScope prof(PROF_UPDATE, 0, 4.0 * (double)total * (g ? 3.25 : 2.25), s);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(jelly_guidance_kernel, dim3(grid), dim3(256), 0, s, io, g, eps_w, eta_J, eta_w, pad_w, sign,
+                       (long long)B * F, Cd, (long long)H * W);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 // ------------------------------------------------------------------ counter-based normal noise
 // Philox4x32-10 keyed by seed; counter = (element/4, draw, trajectory lo, trajectory hi).
 // A trajectory's stream depends only on (seed, global trajectory index, draw): 1-GPU and 8-GPU runs of the

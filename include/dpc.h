@@ -240,6 +240,32 @@ int dpc_ddpm_update_burgers(const float* x, const float* eps_uw, const float* ep
                             const float* u_target, float* x_next, float* x0_out, float* eps_out,
                             const dpc_burgers_coef* coef, int B, int nt, int nx, dpc_stream_t stream);
 
+/* ------------------------------------------------------------------ jellyfish guided update
+ * Replaces diffusion/diffusion_2d_jellyfish.py: model_predictions :703-757 (after the two denoiser calls),
+ * p_mean_variance :759-771, the posterior sample of p_sample :788-790 and of ddim_sample :938-946
+ * (dpc_ddpm_update_jelly), and the guidance step `pred = pred - (eta_J*g - eta_w*pred_noise_w)` :792-804 /
+ * `pred_noise_joint += grad_final` :733-741 (dpc_jelly_apply_guidance).  The gradient g comes from the two learned
+ * 2-D surrogates (autograd, PyTorch-ROCm) and is passed in as a tensor.
+ * x [B,F,Cx,H,W]: Cx = 7 (state 3, boundary 3, theta map 1) or 5 (--only_vis_pressure: pressure, boundary 3, theta);
+ * the diffused channels are x[:, :, :n_state] and x[:, :, Cx-1] -> Cd = n_state + 1 channels in eps / z / pred / x0. */
+typedef struct {
+    float sqrt_recip_ac;     /* :676 */
+    float sqrt_recipm1_ac;   /* :677 */
+    float mean_coef1;        /* posterior_mean_coef1[t] :695 | DDIM sqrt(alpha_next) :943 */
+    float mean_coef2;        /* posterior_mean_coef2[t] :696 | DDIM c :940 */
+    float sigma;             /* exp(0.5*posterior_log_variance_clipped[t]) :790 | DDIM sigma :939 */
+    int32_t clip_denoised;   /* DDPM :763 */
+    int32_t mode;            /* 0 DDPM, 1 DDIM step, 2 DDIM last step (x0) */
+} dpc_jelly_coef;
+/* eps_guided: DDIM only (noise after the guidance term, :741); NULL = eps.  z NULL = no noise.  x0_out may be NULL. */
+int dpc_ddpm_update_jelly(const float* x, const float* eps, const float* eps_guided, const float* z, float* pred,
+                          float* x0_out, const dpc_jelly_coef* coef, int B, int F, int Cx, int n_state, int H, int W,
+                          dpc_stream_t stream);
+/* io[B,F,Cd,H,W] += sign * (eta_J * g - eta_w * w) with w = eps_w [B,F,1,H,W] broadcast over the Cd channels
+ * (pad_w = 0, the DDPM path :800) or zero-padded onto the last channel only (pad_w = 1, :727-732).  g may be NULL. */
+int dpc_jelly_apply_guidance(float* io, const float* g, const float* eps_w, float eta_J, float eta_w, int pad_w,
+                             float sign, int B, int F, int Cd, int H, int W, dpc_stream_t stream);
+
 /* ------------------------------------------------------------------ smoke PDE evaluator (phi rollout)
  * Replaces dataset/apps/evaluate_solver.py `solver` :205-310 (with `get_envolve` :118-147 and the vendored phi it
  * drives: FluidSimulation.divergence_free phi/flow.py:318-327, StaggeredGrid.divergence/gradient/advect

@@ -157,3 +157,130 @@ def gen_burgers_sampler():
 
 
 SECTIONS.update({"unet2d": gen_unet2d, "burgers_sampler": gen_burgers_sampler})
+
+
+# ----------------------------------------------------------------------------- jellyfish 2-D surrogates (C2)
+def gen_jelly_surrogates():
+    from gen_golden import save, sd_arrays
+    from diffusion.diffusion_2d_jellyfish import Unet, ForceUnet
+    from diffphycon_amd.model import surrogates_2d as mine
+
+    torch.manual_seed(4)
+    bd = Unet(dim=8, out_dim=3, dim_mults=(1, 2), channels=3).eval()
+    with torch.no_grad():
+        for n_, p_ in bd.named_parameters():
+            if n_.endswith(".g") or n_.endswith("norm.weight") or n_.endswith("norm.bias"):
+                p_.add_(0.1 * torch.randn_like(p_))
+    x = torch.randn(3, 3, 16, 16)
+    dth = torch.randn(3) * 0.2
+    # ForceUnet ends in Linear(512, out): its bottleneck must be 512 wide (14 M weights).  To keep the fixture small the
+    # weights are NOT stored: they are this repo's module initialised under torch.manual_seed(9) (deterministic CPU
+    # generator), loaded into the reference module, whose output is what gets stored.
+    torch.manual_seed(9)
+    fm_mine = mine.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 8), channels=4)
+    fm = ForceUnet(dim=64, out_dim=1, dim_mults=(1, 8), channels=4).eval()
+    fm.load_state_dict(fm_mine.state_dict())
+    xf = torch.randn(2, 4, 8, 8)
+    with torch.no_grad():
+        y = bd(x, dth)
+        yf = fm(xf)
+    arrays = dict(x=x, dtheta=dth, y=y, xf=xf, yf=yf, fm_seed=9, fm_first_weight=fm_mine.state_dict()["init_conv.weight"][0, 0])
+    arrays.update(sd_arrays(bd, "wbd:"))
+    save("jelly_surrogates", **arrays)
+
+
+SECTIONS.update({"jelly_surrogates": gen_jelly_surrogates})
+
+
+# ----------------------------------------------------------------------------- jellyfish sampler (C1)
+def gen_jelly_sampler():
+    import argparse
+    from gen_golden import save, sd_arrays
+    from model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    import diffusion.diffusion_2d_jellyfish as DJ
+    from torch.autograd import grad
+
+    torch.manual_seed(2)
+    mj = Unet3D_with_Conv3D(dim=8, out_dim=4, dim_mults=(1, 2), channels=7).eval()
+    mw = Unet3D_with_Conv3D(dim=8, out_dim=1, dim_mults=(1, 2), channels=7).eval()
+    bd = DJ.Unet(dim=8, out_dim=3, dim_mults=(1, 2), channels=3).eval()
+    torch.manual_seed(9)
+    from diffphycon_amd.model import surrogates_2d as mine
+    fm_mine = mine.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 8), channels=4)
+    fm = DJ.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 8), channels=4).eval()
+    fm.load_state_dict(fm_mine.state_dict())
+    B, Fr, HW, T = 2, 4, 16, 20
+    p_min, p_max, reg_ratio = -1.7, 2.3, 1000.0
+    g = torch.Generator().manual_seed(8)
+    state_0 = torch.rand(B, 3, HW, HW, generator=g) * 2 - 1
+    bd_0 = torch.rand(B, 3, HW, HW, generator=g)
+    thetas_0 = torch.rand(B, generator=g) * 0.7 + 0.2
+    args = argparse.Namespace(only_vis_pressure=False, device="cpu", reg_ratio=reg_ratio)
+
+    def reg_theta(theta):
+        return torch.sum((theta[:, 1:] - theta[:, :-1]) ** 2, dim=1)
+
+    # force_fn of inference_2d_jellyfish.py:85-114 cannot be imported (the module unpickles a dataset file at import);
+    # this is its call sequence on the reference's own surrogate modules, used only to PRODUCE the reference gradient
+    def design_fn(x, bd0e):
+        state, theta_expand = x[:, :, :3], x[:, :, 3]
+        state.requires_grad_()
+        theta_expand.requires_grad_()
+        theta = torch.mean(torch.mean(theta_expand, dim=3), dim=2)
+        pressure = (0.5 * state[:, :, 2] + 0.5) * (p_max - p_min) + p_min
+        pred_bd = bd(bd0e.reshape(-1, *bd0e.shape[2:]), theta.reshape(-1)).reshape(bd0e.shape)
+        inp = torch.cat((pressure.unsqueeze(2), pred_bd), dim=2)
+        force = fm(inp.reshape(-1, *inp.shape[2:])).reshape(state.shape[0], state.shape[1])
+        weight = torch.FloatTensor(range(force.shape[1], 0, -1)).expand(force.shape[0], force.shape[1])
+        guidance = -torch.mean(force * weight, dim=1) + reg_ratio * reg_theta(theta)
+        gs, gt = grad(guidance, [state, theta_expand], grad_outputs=torch.ones_like(guidance))
+        return torch.cat([gs, gt.unsqueeze(2)], dim=2)
+
+    arrays = dict(state_0=state_0, bd_0=bd_0, thetas_0=thetas_0, p_min=p_min, p_max=p_max, reg_ratio=reg_ratio, fm_seed=9)
+    arrays.update(sd_arrays(mj, "wj:"))
+    arrays.update(sd_arrays(mw, "ww:"))
+    arrays.update(sd_arrays(bd, "wbd:"))
+    xg = torch.rand(B, Fr, 4, HW, HW, generator=g) * 2 - 1
+    arrays["grad:x"] = xg
+    arrays["grad:g"] = design_fn(xg.clone(), bd_0.unsqueeze(1).expand(-1, Fr, -1, -1, -1))
+    for tag, guid, kw in (("alpha", "standard-alpha", dict(coeff_ratio_J=0.3, coeff_ratio_w=0.3)),
+                          ("std", "standard", dict(standard_fixed_ratio=0.003))):
+        gd = DJ.GaussianDiffusion([mj, mw], image_size=HW, frames=Fr, cond_steps=1, timesteps=T, sampling_timesteps=T,
+                                  loss_type="l2", objective="pred_noise", eval_2ddpm=True, device="cpu", **kw)
+        draws = []
+        gen = torch.Generator().manual_seed(12)
+
+        def sample_noise(shape, device, _d=draws, _g=gen):
+            zz = torch.randn(shape, generator=_g)
+            _d.append(zz)
+            return zz
+
+        gd.sample_noise = sample_noise
+        rec = []
+        orig = gd.p_sample
+
+        def p_sample(x, t, *a, _orig=orig, _rec=rec, **k):
+            xin = x.clone()
+            out = _orig(x, t, *a, **k)
+            _rec.append((t, xin, out[0].clone(), out[1].clone()))
+            return out
+
+        gd.p_sample = p_sample
+        with torch.no_grad():
+            states, theta = gd.sample(design_fn=design_fn, design_guidance=guid, cond=[state_0, bd_0], thetas_0=thetas_0,
+                                      bd_updater=bd)
+        arrays[f"{tag}:states"], arrays[f"{tag}:theta"] = states, theta
+        arrays[f"{tag}:noise_init_state"], arrays[f"{tag}:noise_init_bd"], arrays[f"{tag}:noise_init_theta"] = draws[:3]
+        arrays[f"{tag}:noise_steps"] = torch.stack(draws[3:])
+        for (t, xin, pred, x0_) in rec:
+            if t in (19, 7, 0):
+                arrays[f"{tag}:t{t}:x_in"], arrays[f"{tag}:t{t}:pred"], arrays[f"{tag}:t{t}:x0"] = xin, pred, x0_
+                with torch.no_grad():
+                    tb = torch.full((B,), t, dtype=torch.long)
+                    arrays[f"{tag}:t{t}:eps_j"] = mj(xin, tb)
+                    sc = state_0.unsqueeze(1).expand(-1, Fr, -1, -1, -1)
+                    arrays[f"{tag}:t{t}:eps_w"] = mw(torch.cat([sc, xin[:, :, -4:]], dim=2), tb)
+    save("jelly_sampler", **arrays)
+
+
+SECTIONS.update({"jelly_sampler": gen_jelly_sampler})
