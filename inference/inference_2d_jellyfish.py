@@ -1,0 +1,169 @@
+"""2-D jellyfish control inference with the reference's entry surface (inference/inference_2d_jellyfish.py, DDPM
+method): same flags for the sampler, `reg_theta / force_fn / load_model / InferencePipeline.run_model_DDPM` structure,
+running the two space-time U-Nets on libdpc and the two 2-D surrogates on PyTorch-ROCm autograd.
+
+Not carried over: the SAC / MPC baselines and the surrogate-simulator evaluation pipeline (`sim_ppl_2d`), which are
+baselines/ evaluation code outside the sampling hot path.  `--synthetic True` (extra flag) fabricates
+initial states / boundaries / angles and random-initialises all four networks when nothing is mounted under
+JELLYFISH_DATA_PATH; the normalisation constants then default to p in [-1, 1]."""
+import argparse
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from diffphycon_amd.diffusion.diffusion_2d_jellyfish import (ForceUnet, GaussianDiffusion, Trainer, Unet,  # noqa: E402
+                                                             force_fn, reg_theta)
+from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D  # noqa: E402
+from filepath import JELLYFISH_DATA_PATH  # noqa: E402
+
+
+def load_normalization(args):
+    path = os.path.join(args.dataset_path, "train_data/normalization_max_min.pkl")
+    if os.path.exists(path):
+        nd = pickle.load(open(path, "rb"))
+        args.p_max, args.p_min = nd["p_max"], nd["p_min"]
+    elif args.synthetic:
+        args.p_max, args.p_min = 1.0, -1.0
+    else:
+        raise FileNotFoundError(path)
+
+
+def _ddpm(model, args, **kw):
+    return GaussianDiffusion(
+        model, image_size=args.image_size, frames=args.frames, cond_steps=args.cond_steps, timesteps=args.timesteps,
+        sampling_timesteps=min(args.sampling_timesteps, args.timesteps), loss_type="l2", objective="pred_noise",
+        backward_steps=args.backward_steps, backward_lr=args.backward_lr, standard_fixed_ratio=args.standard_fixed_ratio,
+        forward_fixed_ratio=args.forward_fixed_ratio, coeff_ratio_J=args.coeff_ratio_J, coeff_ratio_w=args.coeff_ratio_w,
+        only_vis_pressure=args.only_vis_pressure, device=args.device, **kw)
+
+
+def load_model(args):
+    if args.inference_method != "DDPM":
+        raise NotImplementedError("the SAC / MPC baselines are out of scope (baselines/, sim_ppl_2d)")
+    inp_dim = 5 if args.only_vis_pressure else 7
+    out_dim = 2 if args.only_vis_pressure else 4
+    model_joint = Unet3D_with_Conv3D(dim=64, out_dim=out_dim, dim_mults=(1, 2, 4), channels=inp_dim).to(args.device)
+    diffusion_joint = _ddpm(model_joint, args, eval_2ddpm=False)
+    model_thetas = Unet3D_with_Conv3D(dim=64, out_dim=1, dim_mults=(1, 2, 4), channels=inp_dim).to(args.device)
+    diffusion_thetas = _ddpm(model_thetas, args, eval_2ddpm=False)
+    force_model = ForceUnet(dim=args.image_size, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4)
+    bd_updater = Unet(dim=args.image_size, out_dim=3, dim_mults=(1, 2, 4, 8), channels=3)
+    if not args.synthetic:
+        Trainer(diffusion_joint, results_path=args.diffusion_joint_model_path).load(args.diffusion_joint_checkpoint)
+        Trainer(diffusion_thetas, results_path=args.diffusion_w_model_path).load(args.diffusion_w_checkpoint)
+        force_model.load_state_dict(torch.load(args.force_model_checkpoint, map_location="cpu"))
+        bd_updater.load_state_dict(torch.load(args.boundary_updater_model_checkpoint, map_location="cpu"))
+    force_model.to(args.device).eval()
+    bd_updater.to(args.device).eval()
+    diffusion = _ddpm([diffusion_joint.model, diffusion_thetas.model], args, eval_2ddpm=True, w_prob_exp=args.w_prob_exp,
+                      use_guidance_in_model_predictions=args.use_guidance_in_model_predictions)
+
+    def design_fn(x, bd_0):
+        grad_state, grad_theta = force_fn(x, bd_0, force_model, bd_updater, args)
+        return torch.cat([grad_state, grad_theta.unsqueeze(2)], dim=2)
+
+    return force_model, diffusion, bd_updater, design_fn
+
+
+class InferencePipeline(object):
+    def __init__(self, model, args=None, results_path=None, args_general=None):
+        self.model, self.args, self.results_path, self.args_general = model, args, results_path, args_general
+        for sub in ("", "thetas", "states"):
+            os.makedirs(os.path.join(results_path, sub), exist_ok=True)
+
+    def save(self, sim_id, pred, results_path):
+        pred_states, pred_thetas = pred
+        for index in range(sim_id.shape[0]):
+            i = int(sim_id[index])
+            np.save(os.path.join(results_path, "thetas", f"{i}.npy"), pred_thetas[index].cpu().numpy())
+            np.save(os.path.join(results_path, "states", f"{i}.npy"), pred_states[index].cpu().numpy())
+
+    def run_model_DDPM(self, state_0, bd_0, thetas_0):
+        return self.model.sample(design_fn=self.args["design_fn"], design_guidance=self.args["design_guidance"],
+                                 cond=[state_0, bd_0], thetas_0=thetas_0, bd_updater=self.args["bd_updater"])
+
+    def run(self, batches):
+        objs = []
+        for sim_id, state_0, bd_0, thetas_0 in batches:
+            states, thetas = self.run_model_DDPM(state_0, bd_0, thetas_0)
+            self.save(sim_id, (states, thetas), self.results_path)
+            R = reg_theta(thetas)
+            print(f"batch ids {sim_id.tolist()}: theta range [{thetas.min().item():.3f}, {thetas.max().item():.3f}], "
+                  f"R(theta) mean {R.mean().item():.4e}")
+            objs.append(R.mean().item())
+        print("Final results! mean R(theta):", float(np.mean(objs)))
+        return objs
+
+
+def synthetic_batches(args):
+    """SURVEY.md 8(d) J recipe: state_0 ~ U(-1,1), bd_0 = elliptic mask + offsets in [-1,1], theta_0 ~ U(0.2, 0.9)."""
+    g = torch.Generator().manual_seed(args.seed)
+    s = args.image_size
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, s), torch.linspace(-1, 1, s), indexing="ij")
+    for b in range(args.num_batches):
+        B = args.batch_size
+        state_0 = torch.rand(B, 3, s, s, generator=g) * 2 - 1
+        mask = (((xx - 0.3) / 0.35) ** 2 + (yy / 0.6) ** 2 < 1).float() + (((xx + 0.3) / 0.35) ** 2 + (yy / 0.6) ** 2 < 1).float()
+        bd_0 = torch.stack((mask.clamp(max=1).expand(B, -1, -1), torch.rand(B, s, s, generator=g) * 2 - 1,
+                            torch.rand(B, s, s, generator=g) * 2 - 1), dim=1)
+        thetas_0 = torch.rand(B, generator=g) * 0.7 + 0.2
+        yield torch.arange(b * B, (b + 1) * B), state_0, bd_0, thetas_0
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="inference 2d inverse design model")
+    p.add_argument("--dataset", default="jellyfish", type=str)
+    p.add_argument("--dataset_path", default=JELLYFISH_DATA_PATH, type=str)
+    p.add_argument("--only_vis_pressure", action="store_true")
+    p.add_argument("--use_guidance_in_model_predictions", action="store_true")
+    p.add_argument("--batch_size", default=10, type=int)
+    p.add_argument("--num_batches", default=20, type=int)
+    p.add_argument("--frames", default=20, type=int)
+    p.add_argument("--backward_steps", default=5, type=int)
+    p.add_argument("--backward_lr", default=0.01, type=float)
+    p.add_argument("--standard_fixed_ratio", default=0.003, type=float)
+    p.add_argument("--forward_fixed_ratio", default=0.01, type=float)
+    p.add_argument("--coeff_ratio", default=0.1, type=float)
+    p.add_argument("--coeff_ratio_J", default=0.3, type=float)
+    p.add_argument("--coeff_ratio_w", default=0.3, type=float)
+    p.add_argument("--reg_ratio", default=1000, type=float)
+    p.add_argument("--cond_steps", default=1, type=int)
+    p.add_argument("--diffusion_joint_model_path", default=os.path.join(JELLYFISH_DATA_PATH, "checkpoints"), type=str)
+    p.add_argument("--diffusion_w_model_path", default=os.path.join(JELLYFISH_DATA_PATH, "checkpoints"), type=str)
+    p.add_argument("--diffusion_joint_checkpoint", default=100, type=int)
+    p.add_argument("--diffusion_w_checkpoint", default=50, type=int)
+    p.add_argument("--sampling_timesteps", default=1000, type=int)
+    p.add_argument("--image_size", type=int, default=64)
+    p.add_argument("--inference_result_path", default="./results_jellyfish/", type=str)
+    p.add_argument("--design_guidance", default="standard-alpha", type=str)
+    p.add_argument("--inference_method", default="DDPM", type=str)
+    p.add_argument("--force_model_checkpoint", type=str,
+                   default=os.path.join(JELLYFISH_DATA_PATH, "checkpoints/force_surrogate_model/force_model_epoch_9.pth"))
+    p.add_argument("--boundary_updater_model_checkpoint", type=str,
+                   default=os.path.join(JELLYFISH_DATA_PATH, "checkpoints/boundary_updater/boundary_updater_epoch_9.pth"))
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--w_prob_exp", type=float, default=0.7)
+    # extra (not in the reference)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--synthetic", default=False, type=eval)
+    p.add_argument("--timesteps", default=1000, type=int, help="debug: shorter diffusion chain")
+    return p
+
+
+if __name__ == "__main__":
+    args = build_parser().parse_args()
+    assert torch.cuda.is_available(), "the HIP path needs a GPU"
+    args.device = torch.device("cuda", args.gpu)
+    torch.cuda.set_device(args.device)
+    torch.manual_seed(args.seed)
+    load_normalization(args)
+    force_model, diffusion, bd_updater, design_fn = load_model(args)
+    ppl = InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": args.design_guidance,
+                                        "bd_updater": bd_updater}, results_path=args.inference_result_path, args_general=args)
+    if not args.synthetic:
+        raise NotImplementedError("the Jellyfish dataset reader is a 'next' row (SURVEY.md 8f-3); run with --synthetic True")
+    ppl.run(synthetic_batches(args))

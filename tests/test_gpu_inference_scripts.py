@@ -32,3 +32,10 @@ def test_smoke_inference_script_ddim(tmp_path):
                "--ddim_sampling_steps", "2", "--inference_result_path", str(tmp_path)], ROOT)
     assert "Final results!" in out and "J_total" in out
     assert any(f == "results.txt" for _, _, fs in os.walk(tmp_path) for f in fs)
+
+
+def test_jellyfish_inference_script(tmp_path):
+    out = run(["inference/inference_2d_jellyfish.py", "--synthetic", "True", "--batch_size", "1", "--num_batches", "1",
+               "--frames", "4", "--image_size", "64", "--timesteps", "3", "--inference_result_path", str(tmp_path)], ROOT)
+    assert "Final results!" in out
+    assert os.path.exists(os.path.join(str(tmp_path), "thetas", "0.npy"))
