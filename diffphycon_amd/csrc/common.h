@@ -91,6 +91,7 @@ struct Conv3hParams {
     float* out;             // channels-last [B,F,H,W,N]
     int B, F, H, W;
     int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
+    int dbg;                // perf attribution only (env DPC_CONV_DBG): 1 skip output stores, 2 skip halo loads, 4 skip weight loads
 };
 int launch_conv3h(const Conv3hParams& p, hipStream_t s);
 // same op on the bf16 matrix cores with an exact 3-way bf16 split of both operands (conv3x6.hip); p.wp then points to

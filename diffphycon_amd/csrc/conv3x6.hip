@@ -14,6 +14,8 @@
 // ds_read_b128 with the pitch-12 / lane_hw layout) -- and the 27 taps are LDS offsets.  Weights are pre-split at load
 // time ([tap][chunk][n][3 planes][16] bf16) and double-buffered through LDS one tap ahead.
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:192).
+#include <type_traits>
+
 #include "common.h"
 
 namespace dpc {
@@ -61,7 +63,28 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BN, bool BDIRECT>
+
+// ---- explicit asynchronous loads: the compiler's scheduler sinks ordinary prefetch loads down to their first use
+// (measured: `s_waitcnt vmcnt(0)` a dozen MFMAs after the issue), so the streaming loads of the pipelined kernels are
+// issued with inline asm and retired with hand-counted `s_waitcnt vmcnt(N)`; the waited-for registers are in/out
+// operands of the wait so that no consumer can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ void gload16(bf16x8& dst, const unsigned char* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void gload16f(f32x4& dst, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm3(bf16x8& a, bf16x8& b, bf16x8& c) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm6f(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N) : "memory");
+}
+
+template <int BN, int BDIRECT>
 __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     // 3 waves/SIMD would spill (168 VGPR cap)     // LDS (63/77 KB) admits 2 workgroups/CU
     using namespace x6;
     constexpr int NT = BN / 64;
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && hok[i]) v = *reinterpret_cast<const f32x4*>(src + hoff[i] * cs + cc);
+            if (cok && hok[i] && !(p.dbg & 2)) v = *reinterpret_cast<const f32x4*>(src + hoff[i] * cs + cc);
             hreg[i] = v;
         }
     };
@@ -159,13 +182,169 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
     const int a_lane = (((wm * 2) * HH + lh) * HWD + lw) * PST + hh * 16;
     const int b_lane = (wn * (BN / 2) + l31) * PST + hh * 16;
 
-    if constexpr (BDIRECT) {
+    if constexpr (BDIRECT == 4) {
+        // v4 = v2 with hand-scheduled memory pipeline (see gload16 / wait_vm3): weights two taps ahead in a 3-deep ring,
+        // next-chunk halo issued at tap 0 behind the tap-2 weights, A fragments one tap ahead, vmcnt counted by hand.
+        static_assert(HLOADS == 6, "wait_vm6f assumes 6 halo loads per thread");
+        constexpr int LW = 3 * NT;                     // global loads per ldw
+        const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
+                                     ((long long)n0 + wn * (BN / 2) + l31) * 96 + hh * 16;
+        const long long wstep = (long long)p.Npad * 96;                  // bytes per (tap, chunk)
+        bf16x8 w[3][NT][3];
+        bf16x8 a[2][2][3];
+        auto ldw = [&](int tap, int kc, bf16x8 (&dst)[NT][3]) {
+            const unsigned char* src = wlane + ((long long)tap * p.kchunks + kc) * wstep;
+            gload16<0>(dst[0][0], src); gload16<32>(dst[0][1], src); gload16<64>(dst[0][2], src);
+            if constexpr (NT == 2) { gload16<3072>(dst[1][0], src); gload16<3104>(dst[1][1], src); gload16<3136>(dst[1][2], src); }
+        };
+        auto waitw = [&](auto n, bf16x8 (&r)[NT][3]) {
+            constexpr int N = decltype(n)::value;
+            if constexpr (NT == 2) wait_vm3<N + 3>(r[0][0], r[0][1], r[0][2]);      // first half may retire with 3 more in flight
+            wait_vm3<N>(r[NT - 1][0], r[NT - 1][1], r[NT - 1][2]);
+        };
+        // halo loads: out-of-range / out-of-channel lanes read element 0 and are zeroed after the wait
+        bool hz[HLOADS];
+        auto load_halo_async = [&](int kc) {
+            const int c = kc * KC + hslot;
+            const float* src;
+            int cs, cc;
+            if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+            else { src = p.a1; cs = p.C1; cc = c - p.C0; }
+            const bool cok = c < K;
+#pragma unroll
+            for (int i = 0; i < HLOADS; ++i) {
+                hz[i] = !(cok && hok[i]);
+                gload16f(hreg[i], hz[i] ? p.a0 : src + hoff[i] * cs + cc);
+            }
+        };
+        auto halo_fix = [&]() {
+#pragma unroll
+            for (int i = 0; i < HLOADS; ++i)
+                if (hz[i]) hreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto lda = [&](int tap, bf16x8 (&dst)[2][3]) {
+            const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[mt][pl] = *reinterpret_cast<const bf16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
+        };
+        load_halo_async(0);
+        ldw(0, 0, w[0]);
+        ldw(1, 0, w[1]);
+        wait_vm6f<2 * LW>(hreg[0], hreg[1], hreg[2], hreg[3], hreg[4], hreg[5]);
+        halo_fix();
+        store_halo();
+        __syncthreads();
+        lda(0, a[0]);
+        for (int kc = 0; kc < p.kchunks; ++kc) {
+            const bool more_kc = kc + 1 < p.kchunks;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int t2 = tap + 2;
+                if (t2 < 27) ldw(t2, kc, w[t2 % 3]);
+                else if (more_kc) ldw(t2 - 27, kc + 1, w[t2 % 3]);
+                if (tap == 0 && more_kc) load_halo_async(kc + 1);
+                if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+                // retire w[tap % 3]: count the vector loads issued after it
+                if (more_kc) {
+                    if (tap <= 2) waitw(std::integral_constant<int, 2 * LW + HLOADS>{}, w[tap % 3]);
+                    else if (tap == 3) {          // the halo loads are older than the tap-3 weights: they retire here
+                        waitw(std::integral_constant<int, 2 * LW>{}, w[tap % 3]);
+                        wait_vm6f<2 * LW>(hreg[0], hreg[1], hreg[2], hreg[3], hreg[4], hreg[5]);
+                    } else waitw(std::integral_constant<int, 2 * LW>{}, w[tap % 3]);
+                } else {
+                    if (tap <= 24) waitw(std::integral_constant<int, 2 * LW>{}, w[tap % 3]);
+                    else if (tap == 25) waitw(std::integral_constant<int, LW>{}, w[tap % 3]);
+                    else waitw(std::integral_constant<int, 0>{}, w[tap % 3]);
+                }
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][mt][PA[term]], w[tap % 3][nt][PB[term]],
+                                                                                  acc[mt][nt], 0, 0, 0);
+            }
+            if (more_kc) {
+                halo_fix();
+                __syncthreads();
+                store_halo();
+                __syncthreads();
+                lda(0, a[0]);
+            }
+        }
+    } else if constexpr (BDIRECT == 2) {
+        // v2: weight fragments straight from L2/L1 into a 3-deep register ring (TWO taps ahead; 27 % 3 == 0 keeps the
+        // ring index static across channel chunks), A fragments double-buffered one tap ahead, the 27 taps fully
+        // unrolled (tap offsets are ds_read immediates), and the 6 split-product MFMAs of the 2*NT accumulators issued
+        // round-robin so that no MFMA depends on its predecessor.  The halo prefetch of the next chunk is issued right
+        // after the weight load of tap 2, so the in-order vmcnt only couples it to loads that are needed >= 2 taps later.
+        const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
+                                     ((long long)n0 + wn * (BN / 2) + l31) * 96 + hh * 16;
+        bf16x8 w[3][NT][3];
+        bf16x8 a[2][2][3];
+        auto ldw = [&](int tap, int kc, bf16x8 (&dst)[NT][3]) {
+            const unsigned char* src = wlane + ((p.dbg & 4) ? 0ll : ((long long)tap * p.kchunks + kc) * p.Npad * 96);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) dst[nt][pl] = *reinterpret_cast<const bf16x8*>(src + nt * 32 * 96 + pl * 32);
+        };
+        auto lda = [&](int tap, bf16x8 (&dst)[2][3]) {
+            const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[mt][pl] = *reinterpret_cast<const bf16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
+        };
+        load_halo(0);
+        ldw(0, 0, w[0]);
+        if (p.kchunks > 0) ldw(1, 0, w[1]);
+        store_halo();
+        __syncthreads();
+        lda(0, a[0]);
+        for (int kc = 0; kc < p.kchunks; ++kc) {
+            const bool more_kc = kc + 1 < p.kchunks;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int t2 = tap + 2;
+                if (t2 < 27) ldw(t2, kc, w[t2 % 3]);
+                else if (more_kc) ldw(t2 - 27, kc + 1, w[t2 % 3]);
+                if (tap == 0 && more_kc) load_halo(kc + 1);
+                if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+                asm volatile("" ::: "memory");      // pin the prefetches HERE (the scheduler otherwise sinks them to their use)
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][mt][PA[term]], w[tap % 3][nt][PB[term]],
+                                                                                  acc[mt][nt], 0, 0, 0);
+                asm volatile("" ::: "memory");
+            }
+            if (more_kc) {
+                __syncthreads();
+                store_halo();
+                __syncthreads();
+                lda(0, a[0]);
+            }
+        }
+    } else if constexpr (BDIRECT == 1) {
         // weight fragments straight from L2/L1 into registers, one tap ahead; no barrier inside the tap loop
         const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
                                      ((long long)n0 + wn * (BN / 2) + l31) * 96 + hh * 16;
         bf16x8 wc[NT][3], wnx[NT][3];
         auto ldw = [&](int tap, int kc, bf16x8 (&w)[NT][3]) {
-            const unsigned char* src = wlane + ((long long)tap * p.kchunks + kc) * p.Npad * 96;
+            const unsigned char* src = wlane + ((p.dbg & 4) ? 0ll : ((long long)tap * p.kchunks + kc) * p.Npad * 96);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -281,12 +460,352 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
                 int ih, iw;
                 lane_hw(i, ih, iw);
                 const int h = h0 + ih, w = w0 + iw;
+                if (h < p.H && w < p.W && (!(p.dbg & 1) || acc[mt][nt][r] == 1.2345f))
+                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][nt][r] + bv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent variant: a workgroup walks over work items (tile, n-block) with stride gridDim.x and treats the sequence of
+// (item, channel-chunk) pairs as ONE software pipeline: the halo of the next chunk -- including the first chunk of the
+// NEXT tile -- is prefetched while the current chunk's 27 taps run, the weight ring keeps streaming across item
+// boundaries, and the epilogue stores of a finished tile are issued in front of the next tile's first MFMAs.  This removes
+// the per-workgroup prologue / epilogue bubbles (first halo latency, output burst) that cost ~20 us per launch round with
+// one tile per workgroup (r01 attribution: 0.36 ms of the 1.19 ms 64->64 @ 64x64 launch did not scale with K).
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x6p_kernel(Conv3hParams p, long long nitems) {
+    using namespace x6;
+    constexpr int NT = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / BN;
+    const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH - 1) / TH, ntw = (p.W + TW - 1) / TW;
+    const int K = p.C0 + p.C1;
+    // XCD-contiguous item ranges: workgroup g runs on XCD g % 8; give every XCD one contiguous eighth of the items
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (nwg + 7 - xcd) / 8;
+    const long long per_xcd = (nitems + 7) / 8;
+    const long long xbeg = xcd * per_xcd, xend = (xbeg + per_xcd < nitems) ? xbeg + per_xcd : nitems;
+
+    struct Tile { int n0, b, f0, h0, w0; };
+    auto decode = [&](long long item) {
+        Tile t;
+        t.n0 = (int)(item % ntn) * BN;
+        long long r = item / ntn;
+        t.w0 = (int)(r % ntw) * TW; r /= ntw;
+        t.h0 = (int)(r % nth) * TH; r /= nth;
+        t.f0 = (int)(r % ntf) * TF;
+        t.b = (int)(r / ntf);
+        return t;
+    };
+    // per-thread halo slots (tile independent part)
+    int hdst[HLOADS], hpf[HLOADS], hph[HLOADS], hpw[HLOADS];
+#pragma unroll
+    for (int i = 0; i < HLOADS; ++i) {
+        const int q = tid + 256 * i, pt = q >> 2;
+        hpf[i] = pt / (HH * HWL); hph[i] = (pt / HWL) % HH; hpw[i] = pt % HWL;
+        hdst[i] = (pt < NLOG) ? ((pt / HWL) * HWD + pt % HWL) * PST + (q & 3) * 8 : -1;
+    }
+    const int hslot = (tid & 3) * 4;
+    f32x4 hreg[HLOADS];
+    auto load_halo = [&](const Tile& t, int kc) {
+        const int c = kc * KC + hslot;
+        const float* src;
+        int cs, cc;
+        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        else { src = p.a1; cs = p.C1; cc = c - p.C0; }
+        const bool cok = c < K;
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            const int f = t.f0 - 1 + hpf[i], h = t.h0 - 1 + hph[i], w = t.w0 - 1 + hpw[i];
+            const bool ok = hdst[i] >= 0 && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && ok) v = *reinterpret_cast<const f32x4*>(src + ((((long long)t.b * p.F + f) * p.H + h) * p.W + w) * cs + cc);
+            hreg[i] = v;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            if (hdst[i] >= 0) {
+                uint2 p1, p2, p3;
+                split3(hreg[i], p1, p2, p3);
+                *reinterpret_cast<uint2*>(halo + hdst[i]) = p1;
+                *reinterpret_cast<uint2*>(halo + hdst[i] + 32) = p2;
+                *reinterpret_cast<uint2*>(halo + hdst[i] + 64) = p3;
+            }
+        }
+    };
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    const int a_lane = (((wm * 2) * HH + lh) * HWD + lw) * PST + hh * 16;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.wp) + ((long long)wn * (BN / 2) + l31) * 96 + hh * 16;
+    bf16x8 w[3][NT][3];
+    bf16x8 a[2][2][3];
+    auto ldw = [&](int n0, int tap, int kc, bf16x8 (&dst)[NT][3]) {
+        const unsigned char* src = wbase + (((long long)tap * p.kchunks + kc) * p.Npad + n0) * 96;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[nt][pl] = *reinterpret_cast<const bf16x8*>(src + nt * 32 * 96 + pl * 32);
+    };
+    auto lda = [&](int tap, bf16x8 (&dst)[2][3]) {
+        const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                dst[mt][pl] = *reinterpret_cast<const bf16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
+    };
+    f32x16 acc[2][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    };
+    auto epilogue = [&](const Tile& t) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = t.n0 + wn * (BN / 2) + nt * 32 + l31;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int f = t.f0 + wm * 2 + mt;
+                if (f >= p.F) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    int ih, iw;
+                    lane_hw(i, ih, iw);
+                    const int h = t.h0 + ih, ww = t.w0 + iw;
+                    if (h < p.H && ww < p.W)
+                        p.out[((((long long)t.b * p.F + f) * p.H + h) * p.W + ww) * p.N + n] = acc[mt][nt][r] + bv;
+                }
+            }
+        }
+    };
+
+    long long item = xbeg + wg_in_xcd;
+    if (item >= xend) return;
+    Tile cur = decode(item);
+    zero_acc();
+    load_halo(cur, 0);
+    ldw(cur.n0, 0, 0, w[0]);
+    ldw(cur.n0, 1, 0, w[1]);
+    store_halo();
+    __syncthreads();
+    lda(0, a[0]);
+    while (true) {
+        const long long nitem = item + wgs_per_xcd;
+        const bool more_items = nitem < xend;
+        Tile nxt = cur;
+        if (more_items) nxt = decode(nitem);
+        for (int kc = 0; kc < p.kchunks; ++kc) {
+            const bool last_kc = kc + 1 == p.kchunks;
+            const bool more = !last_kc || more_items;
+            const int nkc = last_kc ? 0 : kc + 1;
+            const int nn0 = last_kc ? nxt.n0 : cur.n0;
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int t2 = tap + 2;
+                if (t2 < 27) ldw(cur.n0, t2, kc, w[t2 % 3]);
+                else if (more) ldw(nn0, t2 - 27, nkc, w[t2 % 3]);
+                if (tap == 0 && more) load_halo(last_kc ? nxt : cur, nkc);
+                if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+                asm volatile("" ::: "memory");      // pin the prefetches HERE (the scheduler otherwise sinks them to their use)
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tap & 1][mt][PA[term]], w[tap % 3][nt][PB[term]],
+                                                                                  acc[mt][nt], 0, 0, 0);
+                asm volatile("" ::: "memory");      // keep the prefetch distance as written: no load hoisting across taps
+            }
+            if (more) {
+                __syncthreads();
+                store_halo();
+                __syncthreads();
+                lda(0, a[0]);
+            }
+            if (last_kc) {
+                epilogue(cur);
+                zero_acc();
+            }
+        }
+        if (!more_items) break;
+        item = nitem;
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// N = 64 layers: 8x4x8 output tile, the four waves stacked along the frame axis, every wave 2 frames x 32 points x all
+// 64 output channels (4 accumulators per wave instead of 2: r01 PMC showed the 2x2-wave BN=64 kernel at 56 % MFMA busy
+// against 76 % for the 4-accumulator BN=128 kernel).  10x6x10 halo = 600 points x 112 B = 66 KB LDS, 2 workgroups / CU.
+namespace x6t {
+using namespace x6;
+constexpr int TF8 = 8;
+constexpr int HF8 = TF8 + 2;
+constexpr int NLOG8 = HF8 * HH * HWL;        // 600 halo points
+constexpr int NSLOT8 = HF8 * HH * HWD;       // 720 LDS slots
+constexpr int HLOADS8 = (NLOG8 * 4 + 255) / 256;
+}  // namespace x6t
+
+__global__ __launch_bounds__(256, 2) void conv3x6t_kernel(Conv3hParams p) {
+    using namespace x6t;
+    constexpr int NT = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;                         // [NSLOT8][PST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / 64;
+    const int ntf = (p.F + TF8 - 1) / TF8, nth = (p.H + TH - 1) / TH, ntw = (p.W + TW - 1) / TW;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n0 = (bid % ntn) * 64;
+    int t = bid / ntn;
+    const int w0 = (t % ntw) * TW; t /= ntw;
+    const int h0 = (t % nth) * TH; t /= nth;
+    const int f0 = (t % ntf) * TF8;
+    const int b = t / ntf;
+    const int K = p.C0 + p.C1;
+
+    long long hoff[HLOADS8];
+    bool hok[HLOADS8];
+    int hdst[HLOADS8];
+#pragma unroll
+    for (int i = 0; i < HLOADS8; ++i) {
+        const int q = tid + 256 * i;
+        const int pt = q >> 2;
+        const int pf = pt / (HH * HWL), ph = (pt / HWL) % HH, pw = pt % HWL;
+        const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
+        hok[i] = pt < NLOG8 && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        hoff[i] = (((long long)b * p.F + f) * p.H + h) * p.W + w;
+        hdst[i] = ((pt / HWL) * HWD + pt % HWL) * PST + (q & 3) * 8;
+    }
+    const int hslot = (tid & 3) * 4;
+    f32x4 hreg[HLOADS8];
+    auto load_halo = [&](int kc) {
+        const int c = kc * KC + hslot;
+        const float* src;
+        int cs, cc;
+        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        else { src = p.a1; cs = p.C1; cc = c - p.C0; }
+        const bool cok = c < K;
+#pragma unroll
+        for (int i = 0; i < HLOADS8; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && hok[i]) v = *reinterpret_cast<const f32x4*>(src + hoff[i] * cs + cc);
+            hreg[i] = v;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HLOADS8; ++i) {
+            if (tid + 256 * i < NLOG8 * 4) {
+                uint2 p1, p2, p3;
+                split3(hreg[i], p1, p2, p3);
+                *reinterpret_cast<uint2*>(halo + hdst[i]) = p1;
+                *reinterpret_cast<uint2*>(halo + hdst[i] + 32) = p2;
+                *reinterpret_cast<uint2*>(halo + hdst[i] + 64) = p3;
+            }
+        }
+    };
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    const int a_lane = (((wm * 2) * HH + lh) * HWD + lw) * PST + hh * 16;
+    const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) + ((long long)n0 + l31) * 96 + hh * 16;
+    bf16x8 wc[NT][3], wnx[NT][3];
+    auto ldw = [&](int tap, int kc, bf16x8 (&w)[NT][3]) {
+        const unsigned char* src = wlane + ((long long)tap * p.kchunks + kc) * p.Npad * 96;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[nt][pl] = *reinterpret_cast<const bf16x8*>(src + nt * 32 * 96 + pl * 32);
+    };
+    load_halo(0);
+    ldw(0, 0, wc);
+    store_halo();
+    __syncthreads();
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+        const bool more_kc = kc + 1 < p.kchunks;
+        if (more_kc) load_halo(kc + 1);
+        for (int tap = 0; tap < 27; ++tap) {
+            const bool last_tap = tap == 26;
+            if (!last_tap || more_kc) ldw(last_tap ? 0 : tap + 1, last_tap ? kc + 1 : kc, wnx);
+            const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[mt][pl] = *reinterpret_cast<const bf16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
+            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[term]], wc[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wc[nt][pl] = wnx[nt][pl];
+        }
+        if (more_kc) {
+            __syncthreads();
+            store_halo();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int f = f0 + wm * 2 + mt;
+            if (f >= p.F) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                int ih, iw;
+                lane_hw(i, ih, iw);
+                const int h = h0 + ih, w = w0 + iw;
                 if (h < p.H && w < p.W)
                     p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][nt][r] + bv;
             }
         }
     }
 }
+
+int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, double flops, double bytes, hipStream_t s);
 
 int conv_mode_default() {
     static const int mode = [] {
@@ -307,28 +826,75 @@ int launch_conv3x6(const Conv3hParams& p, hipStream_t s) {
     const double flops = 2.0 * M * p.N * 27.0 * (p.C0 + p.C1);
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
+    static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
+    Conv3hParams pd = p;
+    pd.dbg = dbg;
+    return launch_conv3x6_impl(pd, wide, tiles, flops, bytes, s);
+}
+
+int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, double flops, double bytes, hipStream_t s) {
+    using namespace x6;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
-    static const int bdirect = [] { const char* e = getenv("DPC_CONV3X6_BDIRECT"); return e ? atoi(e) : 1; }();   // default: direct (measured faster: no per-tap barrier)
+    static const int bdirect = [] { const char* e = getenv("DPC_CONV3X6_BDIRECT"); return e ? atoi(e) : 3; }();   // 0 LDS weights, 1 direct, 2 pipelined direct (BN=64 only), 3 pipelined direct for both widths (default), 4 hand-counted vmcnt
+    static const int tall = [] { const char* e = getenv("DPC_CONV3X6_TALL"); return e ? atoi(e) : 0; }();   // measured = v2, kept opt-in
+    if (tall && !wide && p.F >= 8) {
+        using namespace x6t;
+        DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
+        const long long tiles8 = (long long)p.B * ((p.F + TF8 - 1) / TF8) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+        const long long grid = tiles8 * (p.Npad / 64);
+        DPC_REQUIRE(grid < (1ll << 31), "conv3x6: grid too large");
+        const size_t lds = (size_t)NSLOT8 * PST;
+        static bool once = false;
+        if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+        hipLaunchKernelGGL(conv3x6t_kernel, dim3((unsigned)grid), dim3(256), lds, s, p);
+        DPC_LAUNCH_CHECK();
+        return DPC_OK;
+    }
+    static const int persistent = [] { const char* e = getenv("DPC_CONV3X6_PERSISTENT"); return e ? atoi(e) : 0; }();
+    if (persistent && !wide && p.kchunks >= 1) {
+        DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
+        const long long nitems = tiles * (p.Npad / 64);
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            DPC_HIP(hipGetDevice(&dev));
+            DPC_HIP(hipGetDeviceProperties(&prop, dev));
+            ncu = prop.multiProcessorCount;
+        }
+        const long long grid = std::min<long long>(nitems, (long long)ncu * 2);
+        hipLaunchKernelGGL((conv3x6p_kernel<64>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p, nitems);
+        DPC_LAUNCH_CHECK();
+        return DPC_OK;
+    }
     if (wide) {
         const long long grid = tiles * (p.Npad / 128);
         DPC_REQUIRE(grid < (1ll << 31), "conv3x6: grid too large");
-        if (bdirect) {
-            hipLaunchKernelGGL((conv3x6_kernel<128, true>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        if (bdirect == 4) {
+            hipLaunchKernelGGL((conv3x6_kernel<128, 4>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        } else if (bdirect == 3) {      // v2 at BN = 128 needs > 256 VGPRs (spills): opt-in only
+            hipLaunchKernelGGL((conv3x6_kernel<128, 2>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        } else if (bdirect) {
+            hipLaunchKernelGGL((conv3x6_kernel<128, 1>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
         } else {
             const size_t lds = (size_t)NSLOT * PST + 2 * 128 * PST;
             static bool once = false;
-            if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-            hipLaunchKernelGGL((conv3x6_kernel<128, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+            if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+            hipLaunchKernelGGL((conv3x6_kernel<128, 0>), dim3((unsigned)grid), dim3(256), lds, s, p);
         }
     } else {
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
         const long long grid = tiles * (p.Npad / 64);
         DPC_REQUIRE(grid < (1ll << 31), "conv3x6: grid too large");
-        if (bdirect) {
-            hipLaunchKernelGGL((conv3x6_kernel<64, true>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        if (bdirect == 4) {
+            hipLaunchKernelGGL((conv3x6_kernel<64, 4>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        } else if (bdirect >= 2) {
+            hipLaunchKernelGGL((conv3x6_kernel<64, 2>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
+        } else if (bdirect) {
+            hipLaunchKernelGGL((conv3x6_kernel<64, 1>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
         } else {
             const size_t lds = (size_t)NSLOT * PST + 2 * 64 * PST;
-            hipLaunchKernelGGL((conv3x6_kernel<64, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+            hipLaunchKernelGGL((conv3x6_kernel<64, 0>), dim3((unsigned)grid), dim3(256), lds, s, p);
         }
     }
     DPC_LAUNCH_CHECK();
