@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
         const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
         hok[i] = pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
         hoff[i] = (((long long)b * p.F + f) * p.H + h) * p.W + w;
+        if (p.dbg & 8) hoff[i] = (((long long)0 * p.F + (pf + 1)) * p.H + (ph + 1)) * p.W + (pw + 1);   // perf attribution: L2-resident halo
         hdst[i] = ((pt / HWL) * HWD + pt % HWL) * PST + (q & 3) * 8;      // + plane*32
     }
     const int hslot = (tid & 3) * 4;
