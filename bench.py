@@ -209,8 +209,11 @@ def main_burgers(args, rank, world, device, dist):
         sec = elapsed / args.steps
         name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["flops"] > 0 else d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
-        roof = ({"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS} if d["flops"] > 0 else
+        x6 = name.startswith("igemm") and os.environ.get("DPC_IGEMM_MODE", "x6")[:1].lower() != "f"
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_FP32_MFMA_TFLOPS
+        roof = ({"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                 "peak_note": "2500 TF bf16 dense / 6 MFMAs per fp32 product (bf16x6 split)" if x6 else "fp32 MFMA dense"}
+                if d["flops"] > 0 else
                 {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0})
         roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": d["launches"],
                      "avg_launch_ms": d["total_ms"] / max(d["launches"], 1),
@@ -318,11 +321,12 @@ def main():
             achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
             # conv3x6: every fp32 product costs 6 bf16 MFMAs (exact 3-way split of both operands), so the roof for
             # ALGORITHMIC fp32 flops on that kernel is the dense bf16 MFMA peak / 6; native-fp32 kernels: 157.3 TF
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if name.startswith("conv3x6") else PEAK_FP32_MFMA_TFLOPS
+            x6 = name.startswith("conv3x6") or (name.startswith("igemm") and
+                                                os.environ.get("DPC_IGEMM_MODE", "x6")[:1].lower() != "f")
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x6 else PEAK_FP32_MFMA_TFLOPS
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": pmc_traffic(name),
-                    "peak_note": ("2500 TF bf16 dense / 6 MFMAs per fp32 product (bf16x6 split)"
-                                  if name.startswith("conv3x6") else "fp32 MFMA dense")}
+                    "peak_note": ("2500 TF bf16 dense / 6 MFMAs per fp32 product (bf16x6 split)" if x6 else "fp32 MFMA dense")}
         else:
             achieved = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -340,9 +344,10 @@ def main():
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 in/out and fp32 accumulate everywhere; 3x3x3 convs evaluate each fp32 product as 6 exact "
-                          "bf16 partial products (3-way split, error <= native fp32 MFMA; DPC_CONV_MODE=f32 selects the "
-                          "native fp32 MFMA kernel), all other kernels native fp32 MFMA",
+            "arithmetic": "fp32 in/out and fp32 accumulate everywhere; convolutions and projections outside the fused "
+                          "attention kernels evaluate each fp32 product as 6 exact bf16 partial products (3-way split, error <= "
+                          "native fp32 MFMA; DPC_CONV_MODE=f32 / DPC_IGEMM_MODE=f32 select the native fp32 MFMA kernels), "
+                          "the stem and the fused attention kernels use native fp32 MFMA",
             "config": {"workload": "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames, 1000-step guided DDPM, "
                                    f"batch={B} per GPU; one step = joint+prior Unet3D(dim 64, mults 1-2-4) forward + "
                                    "fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",

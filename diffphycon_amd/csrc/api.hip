@@ -62,7 +62,8 @@ int dpc_philox_normal(float* out, int B, int64_t per_traj, uint64_t seed, int64_
 }
 
 size_t dpc_conv_workspace_bytes(int Cin, int Cout, int ntaps) {
-    return (size_t)ntaps * igemm_kchunks(Cin) * igemm_npad(Cout) * 32 * sizeof(float) + 256;
+    // room for the fp32 pack (128 B per (n, 32-channel chunk, tap)) or the bf16x6 pack (192 B)
+    return (size_t)ntaps * igemm_kchunks(Cin) * igemm_npad(Cout) * 192 + 256;
 }
 
 int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, float* out_cl, int B, int F, int H, int W,
@@ -101,14 +102,16 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
         if (rc) return rc;
         return launch_conv3h(q, s);
     }
-    int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s);
+    const bool x6 = igemm_mode_default() == 1;
+    int rc = x6 ? launch_pack_weights_g6(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s)
+                : launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s);
     if (rc) return rc;
     const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
     p.a0 = x_cl; p.a1 = nullptr; p.C0 = Cin; p.C1 = 0; p.wp = wp; p.bias = bias; p.resid = nullptr; p.out = out_cl;
     p.BF = B * F; p.F = F; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.sh = sh; p.sw = sw;
     p.out_mode = 0;
     p.M = (long long)B * F * Ho * Wo;
-    return launch_igemm(p, s);
+    return x6 ? launch_igemm6(p, wp, s) : launch_igemm(p, s);
 }
 
 int dpc_convtranspose3d_144_cl(const float* x_cl, const float* w_ref, const float* bias, float* out_cl, int B, int F,
@@ -132,13 +135,15 @@ int dpc_convtranspose3d_144_cl(const float* x_cl, const float* w_ref, const floa
                     off[t] = kh_[a][u] * 4 + kh_[b][v];
                 }
             p.N = Cout; p.Npad = igemm_npad(Cout); p.kchunks = igemm_kchunks(Cin); p.ntaps = 4;
-            int rc = launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, 4, 16, (long long)Cout * 16, off, s);
+            const bool x6 = igemm_mode_default() == 1;
+            int rc = x6 ? launch_pack_weights_g6(w_ref, wp, Cout, p.Npad, Cin, 4, 16, (long long)Cout * 16, off, s)
+                        : launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, 4, 16, (long long)Cout * 16, off, s);
             if (rc) return rc;
             p.a0 = x_cl; p.C0 = Cin; p.wp = wp; p.bias = bias; p.out = out_cl;
             p.BF = B * F; p.F = F; p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W; p.sh = 1; p.sw = 1;
             p.out_mode = 2; p.par_a = a; p.par_b = b;
             p.M = (long long)B * F * H * W;
-            rc = launch_igemm(p, s);
+            rc = x6 ? launch_igemm6(p, wp, s) : launch_igemm(p, s);
             if (rc) return rc;
         }
     return DPC_OK;

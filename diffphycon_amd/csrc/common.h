@@ -77,6 +77,12 @@ struct IgemmParams {
 int igemm_npad(int N);
 int igemm_kchunks(int K);
 int launch_igemm(const IgemmParams& p, hipStream_t s);
+// bf16x6 variant of the same op family (igemm6.hip): weights pre-split into [it][Npad][3 planes][32] bf16
+int igemm_mode_default();          // 0: native fp32 MFMA (env DPC_IGEMM_MODE=f32), 1: bf16x6 (default)
+size_t igemm6_packed_bytes(int Npad, int K, int ntaps);
+int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s);
+int launch_pack_weights_g6(const float* w, void* wp6, int N, int Npad, int K, int ntaps, long long stride_n,
+                           long long stride_c, const int* tap_off_host, hipStream_t s);
 // generic weight re-pack: wp[tap][kc][n][kk] = w[n*stride_n + (kc*32+kk)*stride_c + tap_off[tap]]
 int launch_pack_weights(const float* w, float* wp, int N, int Npad, int K, int ntaps, long long stride_n,
                         long long stride_c, const int* tap_off_host, hipStream_t s, int bk = 32);

@@ -117,7 +117,12 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     int rc = pc.wp.alloc((size_t)ntaps * pc.kchunks * pc.Npad * bk * sizeof(float));
     if (rc) return rc;
     rc = launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s, bk);
-    if (rc || !pc.halo) return rc;
+    if (rc) return rc;
+    if (!pc.halo) {
+        if (igemm_mode_default() != 1) return DPC_OK;
+        if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, ntaps)))) return rc;
+        return launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s);
+    }
     if ((rc = pc.wp6.alloc((size_t)27 * pc.kchunks * pc.Npad * 96))) return rc;
     return launch_pack_weights_x6(w, pc.wp6.p, N, pc.Npad, K, s);
 }
@@ -139,7 +144,10 @@ int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b
         }
     int rc = pc.wp.alloc((size_t)4 * pc.kchunks * pc.Npad * 32 * sizeof(float));
     if (rc) return rc;
-    return launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, 4, 16, (long long)N * 16, off, s);
+    if ((rc = launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, 4, 16, (long long)N * 16, off, s))) return rc;
+    if (igemm_mode_default() != 1) return DPC_OK;
+    if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, 4)))) return rc;
+    return launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, 4, 16, (long long)N * 16, off, s);
 }
 
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
@@ -166,6 +174,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
     p.out_mode = out_mode; p.par_a = par_a; p.par_b = par_b;
     for (int i = 0; i < 32; ++i) { p.tdf[i] = pc.tdf[i]; p.tdh[i] = pc.tdh[i]; p.tdw[i] = pc.tdw[i]; }
     p.M = (long long)BF * Ho * Wo;
+    if (pc.wp6g.p) return launch_igemm6(p, pc.wp6g.p, s);
     return launch_igemm(p, s);
 }
 
