@@ -98,7 +98,21 @@ struct Conv3hParams {
     int B, F, H, W;
     int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
     int dbg;                // perf attribution only (env DPC_CONV_DBG): 1 skip output stores, 2 skip halo loads, 4 skip weight loads
+    // GroupNorm fusion (conv3x6 only):
+    float* gn_part;         // out: per-(sample, tile, frame-pair) channel sums of the conv output [B][tiles][2][N][2] (sum, sum sq)
+    const float* in_coef;   // in: GroupNorm+scale/shift coefficients of the INPUT [B][K/4][5][4] (mu, rstd*gamma, beta, scale+1,
+                            //     shift): the halo load applies GN -> (scale, shift) -> SiLU on the fly (requires C1 == 0)
 };
+// tiles per sample of the conv3x6 output tiling (4 x 4 x 8)
+long long conv3x6_tiles_per_sample(int F, int H, int W);
+// stats [B][groups][2] (mean, rstd) and, when coef != null, the per-channel coefficient table consumed by Conv3hParams::in_coef
+int launch_gn_finalize_fused(const float* part, int B, long long tiles, int C, int groups, long long rows_per_sample,
+                             const float* gamma, const float* beta, const float* scale_shift, float* stats, float* coef,
+                             hipStream_t s);
+// GroupNorm apply (+ scale/shift, SiLU, residual) from finished statistics
+int launch_gn_apply(const float* x, float* out, const float* resid, const float* stats, const float* gamma,
+                    const float* beta, const float* scale_shift, int B, long long rows_per_sample, int C, int groups,
+                    hipStream_t s);
 int launch_conv3h(const Conv3hParams& p, hipStream_t s);
 // same op on the bf16 matrix cores with an exact 3-way bf16 split of both operands (conv3x6.hip); p.wp then points to
 // the pre-split weights [27][kchunks][Npad][3][16] bf16 made by launch_pack_weights_x6

@@ -142,7 +142,27 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
             hreg[i] = v;
         }
     };
-    auto store_halo = [&]() {
+    auto store_halo = [&](int kc) {
+        if (p.in_coef) {
+            // fused GroupNorm -> (scale + 1, shift) -> SiLU of the producer (Block.forward, ...conv3d.py:196-204), applied
+            // when the prefetched chunk is split into LDS; the zero padding of the convolution applies to the ACTIVATED
+            // tensor, so out-of-range points stay 0
+            const int c = kc * KC + hslot;
+            if (c < K) {
+                const f32x4* cf = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b * (K >> 2) + (c >> 2)) * 5;
+                const f32x4 mu = cf[0], ga = cf[1], be = cf[2], sc = cf[3], sh = cf[4];
+#pragma unroll
+                for (int i = 0; i < HLOADS; ++i) {
+                    if (hok[i]) {
+                        f32x4 y = (hreg[i] - mu) * ga + be;
+                        y = y * sc + sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
+                        hreg[i] = y;
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             if (tid + 256 * i < NLOG * 4) {
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
         ldw(1, 0, w[1]);
         wait_vm6f<2 * LW>(hreg[0], hreg[1], hreg[2], hreg[3], hreg[4], hreg[5]);
         halo_fix();
-        store_halo();
+        store_halo(0);
         __syncthreads();
         lda(0, a[0]);
         for (int kc = 0; kc < p.kchunks; ++kc) {
@@ -274,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
             if (more_kc) {
                 halo_fix();
                 __syncthreads();
-                store_halo();
+                store_halo(kc + 1);
                 __syncthreads();
                 lda(0, a[0]);
             }
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
         load_halo(0);
         ldw(0, 0, w[0]);
         if (p.kchunks > 0) ldw(1, 0, w[1]);
-        store_halo();
+        store_halo(0);
         __syncthreads();
         lda(0, a[0]);
         for (int kc = 0; kc < p.kchunks; ++kc) {
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
             }
             if (more_kc) {
                 __syncthreads();
-                store_halo();
+                store_halo(kc + 1);
                 __syncthreads();
                 lda(0, a[0]);
             }
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
         };
         load_halo(0);
         ldw(0, 0, wc);
-        store_halo();
+        store_halo(0);
         __syncthreads();
         for (int kc = 0; kc < p.kchunks; ++kc) {
             const bool more_kc = kc + 1 < p.kchunks;
@@ -389,14 +409,14 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
             }
             if (more_kc) {
                 __syncthreads();
-                store_halo();
+                store_halo(kc + 1);
                 __syncthreads();
             }
         }
     } else {
     load_halo(0);
     load_b(0, 0);
-    store_halo();
+    store_halo(0);
     store_b(Bs0);
     __syncthreads();
     int it = 0;
@@ -438,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
             if (has_next) store_b((it & 1) ? Bs0 : Bs1);
             __syncthreads();
             if (last_tap && more_kc) {
-                store_halo();
+                store_halo(kc + 1);
                 __syncthreads();
             }
         }
@@ -449,8 +469,9 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const bool nok = n < p.N;
+        const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int f = f0 + wm * 2 + mt;
@@ -461,8 +482,23 @@ __global__ __launch_bounds__(256, 2) void conv3x6_kernel(Conv3hParams p) {     /
                 int ih, iw;
                 lane_hw(i, ih, iw);
                 const int h = h0 + ih, w = w0 + iw;
-                if (h < p.H && w < p.W && (!(p.dbg & 1) || acc[mt][nt][r] == 1.2345f))
-                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][nt][r] + bv;
+                if (nok && h < p.H && w < p.W && (!(p.dbg & 1) || acc[mt][nt][r] == 1.2345f)) {
+                    const float v = acc[mt][nt][r] + bv;
+                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+        }
+        if (p.gn_part) {
+            // GroupNorm statistics of the OUTPUT: this wave's 2 frames x 32 points of column n (fixed summation order)
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (hh == 0 && nok) {
+                const long long tile = ((long long)(f0 / TF) * nth + h0 / TH) * ntw + w0 / TW;
+                float* dst = p.gn_part + ((((long long)b * ((long long)ntf * nth * ntw) + tile) * 2 + wm) * p.N + n) * 2;
+                dst[0] = ssum;
+                dst[1] = ssq;
             }
         }
     }
@@ -808,6 +844,11 @@ __global__ __launch_bounds__(256, 2) void conv3x6t_kernel(Conv3hParams p) {
 
 int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, double flops, double bytes, hipStream_t s);
 
+long long conv3x6_tiles_per_sample(int F, int H, int W) {
+    using namespace x6;
+    return (long long)((F + TF - 1) / TF) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+}
+
 int conv_mode_default() {
     static const int mode = [] {
         const char* e = getenv("DPC_CONV_MODE");
@@ -838,7 +879,9 @@ int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, doubl
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
     static const int bdirect = [] { const char* e = getenv("DPC_CONV3X6_BDIRECT"); return e ? atoi(e) : 3; }();   // 0 LDS weights, 1 direct, 2 pipelined direct (BN=64 only), 3 pipelined direct for both widths (default), 4 hand-counted vmcnt
     static const int tall = [] { const char* e = getenv("DPC_CONV3X6_TALL"); return e ? atoi(e) : 0; }();   // measured = v2, kept opt-in
-    if (tall && !wide && p.F >= 8) {
+    const bool fused_gn = p.gn_part || p.in_coef;          // only the default kernels implement the GroupNorm fusion
+    DPC_REQUIRE(!(p.in_coef && p.C1 != 0), "conv3x6: fused input normalisation needs a single source");
+    if (tall && !wide && p.F >= 8 && !fused_gn) {
         using namespace x6t;
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
         const long long tiles8 = (long long)p.B * ((p.F + TF8 - 1) / TF8) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
@@ -852,7 +895,7 @@ int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, doubl
         return DPC_OK;
     }
     static const int persistent = [] { const char* e = getenv("DPC_CONV3X6_PERSISTENT"); return e ? atoi(e) : 0; }();
-    if (persistent && !wide && p.kchunks >= 1) {
+    if (persistent && !wide && p.kchunks >= 1 && !fused_gn) {
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
         const long long nitems = tiles * (p.Npad / 64);
         static int ncu = 0;

@@ -215,6 +215,97 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
     }
 }
 
+// ---- fused-statistics path: the conv3x6 epilogue already produced per-tile channel sums (Conv3hParams::gn_part)
+// one wave per (sample, group): fold [tiles][2][C][2] fp32 partials in fp64 (fixed order), emit (mean, rstd) and the
+// per-channel coefficient table [B][C/4][5][4] = (mu, rstd*gamma, beta, scale+1, shift) for the consumer's halo load
+__global__ __launch_bounds__(256) void gn_finalize_fused_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                float* __restrict__ coef, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ scale_shift, long long tiles, int C,
+                                                                int groups, long long R, int B) {
+    // one WORKGROUP per (sample, group): 256 threads stream the partials with 4 independent accumulators each (the
+    // one-wave version was latency-bound: 64 waves on the whole GPU, 256 dependent iterations per lane)
+    __shared__ double red_s[256], red_q[256];
+    const int tid = threadIdx.x;
+    const int wid = blockIdx.x;
+    const int b = wid / groups, g = wid % groups;
+    const int cpg = C / groups;
+    const long long nslab = tiles * 2, total = nslab * cpg;
+    const float* base = part + ((long long)b * nslab * C + (long long)g * cpg) * 2;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    auto at = [&](long long i) -> const float* {
+        const long long k = i / cpg;
+        const int c = (int)(i - k * cpg);
+        return base + (k * C + c) * 2;
+    };
+    long long i = tid;
+    for (; i + 768 < total; i += 1024) {
+        const float *p0 = at(i), *p1 = at(i + 256), *p2 = at(i + 512), *p3 = at(i + 768);
+        const float a0 = p0[0], b0 = p0[1], a1 = p1[0], b1 = p1[1], a2 = p2[0], b2 = p2[1], a3 = p3[0], b3 = p3[1];
+        s0 += (double)a0; q0 += (double)b0; s1 += (double)a1; q1 += (double)b1;
+        s2 += (double)a2; q2 += (double)b2; s3 += (double)a3; q3 += (double)b3;
+    }
+    for (; i < total; i += 256) {
+        const float* p0 = at(i);
+        s0 += (double)p0[0];
+        q0 += (double)p0[1];
+    }
+    red_s[tid] = (s0 + s1) + (s2 + s3);
+    red_q[tid] = (q0 + q1) + (q2 + q3);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red_s[tid] += red_s[tid + o]; red_q[tid] += red_q[tid + o]; }
+        __syncthreads();
+    }
+    const double n = (double)R * cpg;
+    const double mean = red_s[0] / n;
+    double var = red_q[0] / n - mean * mean;
+    if (var < 0) var = 0;
+    const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + 1e-5));
+    if (tid == 0) {
+        stats[2 * wid] = mu;
+        stats[2 * wid + 1] = rstd;
+    }
+    if (coef) {
+        for (int c = tid; c < cpg; c += 256) {
+            const int ch = g * cpg + c;
+            float* dst = coef + ((long long)b * (C >> 2) + (ch >> 2)) * 20 + (ch & 3);
+            dst[0] = mu;
+            dst[4] = rstd * gamma[ch];
+            dst[8] = beta[ch];
+            dst[12] = scale_shift ? scale_shift[(long long)b * 2 * C + ch] + 1.0f : 1.0f;
+            dst[16] = scale_shift ? scale_shift[(long long)b * 2 * C + C + ch] : 0.0f;
+        }
+    }
+}
+
+int launch_gn_finalize_fused(const float* part, int B, long long tiles, int C, int groups, long long R,
+                             const float* gamma, const float* beta, const float* scale_shift, float* stats, float* coef,
+                             hipStream_t s) {
+    DPC_REQUIRE(groups >= 1 && C % groups == 0 && C % 4 == 0, "gn_finalize_fused: groups must divide C, C % 4 == 0");
+    if (B == 0) return DPC_OK;
+    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * tiles * 2 * C * 2, s);
+    hipLaunchKernelGGL(gn_finalize_fused_kernel, dim3(B * groups), dim3(256), 0, s, part, stats, coef, gamma, beta,
+                       scale_shift, tiles, C, groups, R, B);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int launch_gn_apply(const float* x, float* out, const float* resid, const float* stats, const float* gamma,
+                    const float* beta, const float* scale_shift, int B, long long R, int C, int groups, hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0, "groupnorm: C/4 must divide 256");
+    if (B == 0 || R == 0) return DPC_OK;
+    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * R * C * (resid ? 3 : 2), s);
+    const int rpp = 256 / (C / 4);
+    long long nblk = R / ((long long)rpp * 8);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, out, resid, stats, gamma, beta, scale_shift, R,
+                       C, groups, (int)nblk);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 int launch_groupnorm_silu(const float* x, float* out, const float* resid, const float* gamma, const float* beta,
                           const float* scale_shift, int B, long long R, int C, int groups, void* ws, hipStream_t s) {
     DPC_REQUIRE(C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0, "groupnorm: C/4 must divide 256");

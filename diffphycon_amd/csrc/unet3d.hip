@@ -23,6 +23,7 @@ struct dpc_unet3d_s {
     dpc::DevBuf t_bias, t_cos, t_sin, t_freq;
     bool finalized = false;
     bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 selects the unfused reference composition (A/B tests)
+    bool fused_gn = true;        // DPC_UNFUSED_GN=1: standalone GroupNorm passes (3 per norm) instead of the conv-fused form
     // debug taps
     bool taps_on = false;
     struct Tap { std::unique_ptr<dpc::DevBuf> buf; size_t floats = 0; };
@@ -152,13 +153,16 @@ int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b
 
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
-             const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s) {
+             const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part,
+             const float* in_coef) {
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
+    DPC_REQUIRE(!(gn_part || in_coef) || (pc.halo && conv_mode_default() == 1), "conv: GroupNorm fusion needs the conv3x6 path");
     if (pc.halo) {
         DPC_REQUIRE(!resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo, "conv3h: plain 3x3x3 conv only");
         Conv3hParams q{};
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = pc.wp.f(); q.bias = bias; q.out = out;
         q.B = BF / F; q.F = F; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = pc.kchunks;
+        q.gn_part = gn_part; q.in_coef = in_coef;
         if (conv_mode_default() == 1) {
             q.wp = reinterpret_cast<const float*>(pc.wp6.p);
             return launch_conv3x6(q, s);
@@ -240,9 +244,42 @@ struct Runner {
             RUN(launch_small_linear(temb, raw(p + ".mlp.1.weight"), raw(p + ".mlp.1.bias"), ss, mb, h->cfg.dim * 4,
                                     2 * Cout, 1, 0, s));
         }
+        const bool same = (C1 == 0 && C0 == Cout);
+        if (h->fused_gn && conv_mode_default() == 1) {
+            // GroupNorm fused around the two conv3x6 launches: statistics come out of the conv epilogues, block1's
+            // normalise + scale/shift + SiLU is applied inside block2's halo load (h1 never exists in HBM in activated
+            // form), only block2's normalise + SiLU (+ residual) is a separate streaming pass.
+            const long long tiles = conv3x6_tiles_per_sample(F, Hl, Wl);
+            const long long R = (long long)F * Hl * Wl;
+            float* raw1 = ar.allocf(P * Cout);
+            float* part = ar.allocf((long long)mb * tiles * 2 * Cout * 2);
+            float* stats = ar.allocf((long long)mb * Cout * 2);
+            float* coef = ar.allocf((long long)mb * Cout * 5);
+            float* raw2 = (same && dst == x0) ? ar.allocf(P * Cout) : dst;      // (allocated in the dry run as well)
+            const PackedConv* c1 = conv(p + ".block1.proj.weight");
+            const PackedConv* c2 = conv(p + ".block2.proj.weight");
+            if (c1 && c2) {
+                RUN(run_conv(*c1, x0, x1, C0, C1, raw(p + ".block1.proj.bias"), nullptr, raw1, mb * F, F, Hl, Wl, Hl, Wl, nullptr,
+                             nullptr, 0, 0, 0, s, part, nullptr));
+                RUN(launch_gn_finalize_fused(part, mb, tiles, Cout, h->cfg.groups, R, raw(p + ".block1.norm.weight"),
+                                             raw(p + ".block1.norm.bias"), ss, stats, coef, s));
+                RUN(run_conv(*c2, raw1, nullptr, Cout, 0, raw(p + ".block2.proj.bias"), nullptr, raw2, mb * F, F, Hl, Wl, Hl, Wl,
+                             nullptr, nullptr, 0, 0, 0, s, part, coef));
+                RUN(launch_gn_finalize_fused(part, mb, tiles, Cout, h->cfg.groups, R, nullptr, nullptr, nullptr, stats, nullptr, s));
+                RUN(launch_gn_apply(raw2, dst, same ? x0 : nullptr, stats, raw(p + ".block2.norm.weight"),
+                                    raw(p + ".block2.norm.bias"), nullptr, mb, R, Cout, h->cfg.groups, s));
+            }
+            if (!same) {
+                const PackedConv* rcv = conv(p + ".res_conv.weight");
+                if (rcv)
+                    RUN(run_conv(*rcv, x0, x1, C0, C1, raw(p + ".res_conv.bias"), dst, dst, mb * F, F, Hl, Wl, Hl, Wl,
+                                 nullptr, nullptr, 0, 0, 0, s));
+            }
+            ar.release(m);
+            return;
+        }
         float* h1 = ar.allocf(P * Cout);
         block(p + ".block1", x0, x1, C0, C1, Cout, h1, h1, nullptr, ss, Hl, Wl);
-        const bool same = (C1 == 0 && C0 == Cout);
         if (same) {
             float* h2 = (dst == x0) ? ar.allocf(P * Cout) : dst;
             block(p + ".block2", h1, nullptr, Cout, 0, Cout, h2, dst, x0, nullptr, Hl, Wl);   // + x (identity res_conv)
@@ -462,6 +499,7 @@ int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out) {
     auto* h = new dpc_unet3d_s();
     h->cfg = *cfg;
     if (const char* e = getenv("DPC_UNFUSED_ATTN")) h->fused_attn = !(e[0] == '1');
+    if (const char* e = getenv("DPC_UNFUSED_GN")) h->fused_gn = !(e[0] == '1');
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
     for (int i = 0; i < cfg->n_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);

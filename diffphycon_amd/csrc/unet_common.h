@@ -53,6 +53,7 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
                 int pw, hipStream_t s);
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
-             const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s);
+             const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part = nullptr,
+             const float* in_coef = nullptr);
 
 }  // namespace dpc
