@@ -166,6 +166,11 @@ struct StemParams {
     long long M;
 };
 int launch_stem(const StemParams& p, hipStream_t s);
+// bf16x6 LDS-halo variant for the 7x7x7 kernel with <= 8 input channels (stem7x6.hip)
+bool stem7x6_supported(int C, int k);
+size_t stem7x6_packed_bytes(int Npad);
+int launch_pack_stem7x6(const float* w, void* wp6, int N, int Npad, int C, hipStream_t s);
+int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s);
 int launch_pack_stem(const float* w, float* wp, int* ktab, int N, int Npad, int C, int k, hipStream_t s, int kd = 0);
 
 // ---------------------------------------------------------------- norms (norm.hip)

@@ -1,0 +1,223 @@
+// 7x7x7 stem convolution (init_conv of Unet3D_with_Conv3D, video_diffusion_pytorch_conv3d.py:392: nn.Conv3d(channels, dim,
+// 7, padding 3)) with fp32 semantics on the bf16 matrix cores (exact 3-way split, 6 MFMAs per product, see conv3x6.hip).
+//
+// The gather-per-K-element kernel in igemm.hip (stem_kernel) spends its time issuing 4-byte global loads (r01: 34 % MFMA
+// busy, 52 TF/s).  Here a workgroup stages the 10 x 10 x 14 input halo of its 4 x 4 x 8 output tile ONCE in LDS, already
+// split into three bf16 planes and padded to 8 channels per point (16 B "slots"), and walks the 49 (df, dh) tap rows; a
+// tap row's (dw, c) pairs are then one contiguous run of 8 slots = 64 k-values = 4 MFMA k-steps whose A fragments are plain
+// 16-byte LDS reads (k-step s covers dw = 2s, 2s+1; the 8th w-tap and channels >= C carry zero weights: 42 of 64 k-values
+// are useful for C = 6).  Rows are 16 slots = 256 B; rows whose (h >> 1) is odd are rotated by 8 slots, so the two rows a
+// ds_read_b128 pass touches (h and h+2, see lane_hw in conv3x6.hip) always hit complementary bank halves: conflict-free.
+// Weights are pre-split [49][4][n][3 planes][16] bf16 and read as fragments straight from L2/L1, one k-step ahead.
+#include "common.h"
+
+namespace dpc {
+
+namespace s7 {
+constexpr int TF = 4, TH = 4, TW = 8;
+constexpr int HF = TF + 6, HH = TH + 6, HWL = TW + 6;      // 10 x 10 x 14 logical halo
+constexpr int SLOTS = 16;                                  // slots per row (15 addressed: w + 2*3 + 1 <= 14)
+constexpr int ROWB = SLOTS * 16;                           // 256 B
+constexpr int PLANEB = HF * HH * ROWB;                     // 25 600 B per plane
+constexpr int NPT = HF * HH * SLOTS;                       // point slots to fill (1600, incl. the zero slots 14, 15)
+
+__device__ __forceinline__ void lane_hw(int i, int& h, int& w) {      // same service-group aware map as conv3x6.hip
+    if (i < 4) { h = 0; w = i; }
+    else if (i < 12) { h = 1; w = i - 4; }
+    else if (i < 16) { h = 0; w = i - 8; }
+    else if (i < 20) { h = 3; w = i - 16; }
+    else if (i < 28) { h = 2; w = i - 20; }
+    else { h = 3; w = i - 24; }
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float lo_f32(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float hi_f32(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+// exact 3-way split of 2 floats -> one packed pair per plane
+__device__ __forceinline__ void split3_2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = cvt_pk_bf16(a, b);
+    const float r0 = a - lo_f32(p1), r1 = b - hi_f32(p1);
+    p2 = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - lo_f32(p2), s1 = r1 - hi_f32(p2);
+    p3 = cvt_pk_bf16(s0, s1);
+}
+}  // namespace s7
+
+typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const unsigned char* __restrict__ wp6) {
+    using namespace s7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    unsigned char* halo = smem7;                                  // [3 planes][HF][HH][16 slots][8 ch] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / 64;
+    const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH - 1) / TH, ntw = (p.W + TW - 1) / TW;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n0 = (bid % ntn) * 64;
+    int t = bid / ntn;
+    const int w0 = (t % ntw) * TW; t /= ntw;
+    const int h0 = (t % nth) * TH; t /= nth;
+    const int f0 = (t % ntf) * TF;
+    const int b = t / ntf;
+    const long long HWin = (long long)p.H * p.W;
+
+    // ---- stage the halo: one thread per point slot; out-of-range points, slots 14/15 and channels >= C are zero
+    for (int q = tid; q < NPT; q += 256) {
+        const int slot = q % SLOTS, row = q / SLOTS;              // row = pf * HH + ph
+        const int pf = row / HH, ph = row % HH;
+        const int f = f0 - 3 + pf, h = h0 - 3 + ph, w = w0 - 3 + slot;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 0.f;
+        if (slot < HWL && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+            const float* src = p.x + (((long long)b * p.F + f) * p.Ctot + p.c_off) * HWin + (long long)h * p.W + w;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < p.C) v[c] = src[(long long)c * HWin];
+        }
+        u32x4 q1, q2, q3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned a1, a2, a3;
+            split3_2(v[2 * c], v[2 * c + 1], a1, a2, a3);
+            q1[c] = a1; q2[c] = a2; q3[c] = a3;
+        }
+        const int rslot = (slot + (((ph >> 1) & 1) << 3)) & 15;   // bank rotation of rows with odd (h >> 1)
+        unsigned char* dst = halo + row * ROWB + rslot * 16;
+        *reinterpret_cast<u32x4*>(dst) = q1;
+        *reinterpret_cast<u32x4*>(dst + PLANEB) = q2;
+        *reinterpret_cast<u32x4*>(dst + 2 * PLANEB) = q3;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    // weight fragments: [(df*7+dh)*4 + ks][Npad][3][16] bf16 = 96 B per n
+    const unsigned char* wlane = wp6 + ((long long)n0 + wn * 32 + l31) * 96 + hh * 16;
+    const long long wstep = (long long)p.Npad * 96;
+    bf16x8_s wc[3], wx[3];
+    auto ldw = [&](int step, bf16x8_s (&w)[3]) {
+        const unsigned char* src = wlane + (long long)step * wstep;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8_s*>(src + pl * 32);
+    };
+    ldw(0, wc);
+    __syncthreads();
+
+    for (int df = 0; df < 7; ++df) {
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh) {
+            const int row0 = ((wm * 2 + df) * HH + lh + dh) * ROWB;           // frame wm*2 (+ mt), halo row lh + dh
+            const int rot = (((lh + dh) >> 1) & 1) << 3;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int step = (df * 7 + dh) * 4 + ks;
+                if (step + 1 < 196) ldw(step + 1, wx);
+                const int slot = (lw + 2 * ks + hh + rot) & 15;
+                bf16x8_s a[2][3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[mt][pl] = *reinterpret_cast<const bf16x8_s*>(halo + pl * PLANEB + row0 + mt * (HH * ROWB) + slot * 16);
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wc[pl] = wx[pl];
+            }
+        }
+    }
+
+    const int n = n0 + wn * 32 + l31;
+    if (n < p.N) {
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int f = f0 + wm * 2 + mt;
+            if (f >= p.F) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                int ih, iw;
+                lane_hw(i, ih, iw);
+                const int h = h0 + ih, w = w0 + iw;
+                if (h < p.H && w < p.W)
+                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][r] + bv;
+            }
+        }
+    }
+}
+
+bool stem7x6_supported(int C, int k) { return k == 7 && C >= 1 && C <= 8; }
+size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }
+
+int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
+    using namespace s7;
+    DPC_REQUIRE(p.Npad % 64 == 0 && wp6, "stem7x6: Npad must be a multiple of 64 and weights packed");
+    DPC_REQUIRE(p.C >= 1 && p.C <= 8, "stem7x6: at most 8 input channels");
+    if (p.M == 0) return DPC_OK;
+    const int B = p.BF / p.F;
+    const long long tiles = (long long)B * ((p.F + TF - 1) / TF) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const long long grid = tiles * (p.Npad / 64);
+    DPC_REQUIRE(grid < (1ll << 31), "stem7x6: grid too large");
+    const size_t lds = 3 * (size_t)PLANEB;
+    ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * 343.0 * p.C, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
+    static bool once = false;
+    if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
+    hipLaunchKernelGGL(stem7x6_kernel, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// reference weight [N][C][7][7][7] fp32 -> [(df*7+dh)*4 + ks][Npad][3 planes][16] bf16, k = (dw - 2 ks) * 8 + c
+__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C) {
+    const long long total = 196ll * Npad * 16;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % 16);
+        long long r = i / 16;
+        const int n = (int)(r % Npad);
+        const int step = (int)(r / Npad);
+        const int ks = step & 3, tap = step >> 2, df = tap / 7, dh = tap % 7;
+        const int dw = 2 * ks + (kk >> 3), c = kk & 7;
+        float v = 0.f;
+        if (n < N && c < C && dw < 7) v = w[(((long long)n * C + c) * 7 + df) * 49 + dh * 7 + dw];
+        const unsigned p1 = s7::cvt_pk_bf16(v, 0.f) & 0xffffu;
+        const float r1 = v - __uint_as_float(p1 << 16);
+        const unsigned p2 = s7::cvt_pk_bf16(r1, 0.f) & 0xffffu;
+        const float r2 = r1 - __uint_as_float(p2 << 16);
+        const unsigned p3 = s7::cvt_pk_bf16(r2, 0.f) & 0xffffu;
+        unsigned short* dst = wp + ((long long)step * Npad + n) * 48 + kk;
+        dst[0] = (unsigned short)p1;
+        dst[16] = (unsigned short)p2;
+        dst[32] = (unsigned short)p3;
+    }
+}
+
+int launch_pack_stem7x6(const float* w, void* wp6, int N, int Npad, int C, hipStream_t s) {
+    const long long total = 196ll * Npad * 16;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_stem7x6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad, C);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+}  // namespace dpc

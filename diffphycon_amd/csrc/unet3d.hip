@@ -15,7 +15,7 @@ struct dpc_unet3d_s {
     std::vector<int> dims;                                  // [init_dim, dim*m0, dim*m1, ...]
     std::map<std::string, std::unique_ptr<dpc::DevBuf>> raw;        // reference-layout small params
     std::map<std::string, std::unique_ptr<dpc::PackedConv>> conv;   // packed GEMM operands (ups.*.4 -> name#ab)
-    std::unique_ptr<dpc::DevBuf> stem_wp, stem_ktab;
+    std::unique_ptr<dpc::DevBuf> stem_wp, stem_ktab, stem_wp6;     // stem_wp6: pre-split weights of the LDS-halo bf16x6 stem
     int stem_npad = 0, stem_kchunks = 0;
     std::set<std::string> loaded;
     // tables
@@ -392,7 +392,8 @@ struct Runner {
             sp.bias = raw("init_conv.bias"); sp.out = X0; sp.BF = mb * F; sp.F = F; sp.C = c.channels; sp.H = H; sp.W = W;
             sp.Ctot = x_ctot; sp.c_off = x_coff;
             sp.N = dim; sp.Npad = h->stem_npad; sp.kchunks = h->stem_kchunks; sp.M = P0;
-            RUN(launch_stem(sp, s));
+            if (!dry() && h->stem_wp6) RUN(launch_stem7x6(sp, h->stem_wp6->p, s));
+            else RUN(launch_stem(sp, s));
         }
         tap("init_conv", X0, dim, H, W);
         attention("init_temporal_attn", X0, dim, H, W, true);
@@ -531,6 +532,13 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
         if ((rc = h->stem_wp->alloc((size_t)h->stem_kchunks * h->stem_npad * 32 * sizeof(float)))) return rc;
         if ((rc = h->stem_ktab->alloc((size_t)h->stem_kchunks * 32 * sizeof(int)))) return rc;
         rc = launch_pack_stem(w, h->stem_wp->f(), (int*)h->stem_ktab->p, N, h->stem_npad, C, k, s);
+        static const bool stem_f32 = [] { const char* e = getenv("DPC_STEM_MODE"); return e && (e[0] == 'f' || e[0] == 'F'); }();
+        h->stem_wp6.reset();
+        if (!rc && !stem_f32 && stem7x6_supported(C, k)) {
+            h->stem_wp6.reset(new DevBuf());
+            if ((rc = h->stem_wp6->alloc(stem7x6_packed_bytes(h->stem_npad)))) return rc;
+            rc = launch_pack_stem7x6(w, h->stem_wp6->p, N, h->stem_npad, C, s);
+        }
     } else if (name.rfind("ups.", 0) == 0 && ends_with(name, ".4.weight")) {
         DPC_REQUIRE(ndim == 5 && shape[2] == 1 && shape[3] == 4 && shape[4] == 4, "ConvTranspose3d weight must be [Cin,Cout,1,4,4]");
         for (int a = 0; a < 2 && !rc; ++a)
