@@ -93,6 +93,11 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
         Conv3hParams q{};
         q.a0 = x_cl; q.C0 = Cin; q.wp = wp; q.bias = bias; q.out = out_cl;
         q.B = B; q.F = F; q.H = H; q.W = W; q.N = Cout; q.Npad = p.Npad; q.kchunks = (Cin + 15) / 16;
+        if (conv_mode_default() == 2) {
+            int rc = launch_pack_weights_f3(w_ref, wp, Cout, p.Npad, Cin, s);     // 64 B per (tap, chunk, n)
+            if (rc) return rc;
+            return launch_conv3f3(q, s);
+        }
         if (conv_mode_default() == 1) {
             int rc = launch_pack_weights_x6(w_ref, wp, Cout, p.Npad, Cin, s);     // 96 B per (tap, chunk, n) <= fp32 pack size
             if (rc) return rc;

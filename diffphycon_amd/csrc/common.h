@@ -118,7 +118,10 @@ int launch_conv3h(const Conv3hParams& p, hipStream_t s);
 // the pre-split weights [27][kchunks][Npad][3][16] bf16 made by launch_pack_weights_x6
 int launch_conv3x6(const Conv3hParams& p, hipStream_t s);
 int launch_pack_weights_x6(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
-// 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6); env DPC_CONV_MODE=f32|x6, default x6
+// same op with a 2-way fp16 split (22-bit operands, 3 MFMAs per product; conv3f3.hip); p.wp = [27][kchunks][Npad][2][16] fp16
+int launch_conv3f3(const Conv3hParams& p, hipStream_t s);
+int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
+// 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6), 2: f16x3 split (conv3f3); env DPC_CONV_MODE=f32|x6|f16x3, default f16x3
 int conv_mode_default();
 
 // Fused Residual(PreNorm(temporal Attention)) (tattn_fused.hip); weights in the reference layout
@@ -131,9 +134,11 @@ struct TattnParams {
     const float* rot_cos;   // [F][32]
     const float* rot_sin;
     const float* bias;      // [4][F][F]
+    const float* bias32;    // the same table zero-padded to [4][32][32] (bf16x6 kernel: 16-byte row loads)
     long long npix;         // B*HW sequences
     long long HW;
     int F;
+    int dbg;                // DPC_TATTN_DBG experiment bits (0 in production)
 };
 // Fused Residual(PreNorm(SpatialLinearAttention)) (lattn_fused.hip); weights in the reference layout
 struct LattnParams {
@@ -152,6 +157,11 @@ size_t lattn_fused_workspace_bytes(long long images);
 int launch_lattn_fused(const LattnParams& p, int C, hipStream_t s);
 bool tattn_fused_supported(int C, int F, int heads);
 int launch_tattn_fused(const TattnParams& p, int C, hipStream_t s);
+// bf16x6 versions (tattn6.hip / lattn6.hip): weights pre-split at load time into per-head LDS images
+size_t attn6_qkv_bytes(int C);
+size_t attn6_out_bytes(int C);
+int launch_pack_attn6(const float* w, unsigned char* dst, int C, bool is_out, hipStream_t s);
+int launch_tattn6(const TattnParams& p, const unsigned char* wq6, const unsigned char* wo6, int C, hipStream_t s);
 
 // "gather" variant for the 7x7x7 stem on the reference-layout input [BF, C, H, W] (K = taps*C flattened)
 struct StemParams {

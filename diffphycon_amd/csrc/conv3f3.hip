@@ -1,0 +1,323 @@
+// Conv3d 3x3x3 / stride 1 / pad 1, channels-last, on the fp16 matrix cores with split operands ("f16x3").
+//
+// Every fp32 operand x is pre-scaled by a power of two (activations 2^4, weights 2^12: keeps both split terms inside
+// fp16's narrow exponent range) and written as  x = h1 + h2 + e  with h1 = fp16(x), h2 = fp16(x - h1) (round to nearest):
+// 22 significant bits, |e| <= 2^-22 |x|.  A product is the three partial products of weight >= 2^-11
+//        a1 b1 + (a1 b2 + a2 b1)
+// each exact in fp32 (11 x 11-bit significands) and accumulated in fp32 by v_mfma_f32_32x32x16_f16; the dropped a2 b2 term
+// and the split remainders are <= 3 * 2^-22 relative per product.  On a K = 27 x 64 convolution this is BELOW the fp32
+// accumulation error of the sum itself: against fp64 the result is as accurate as the 6-product bf16 scheme of
+// conv3x6.hip (tools/f16x3_error.py: rms 1.2e-6 vs 1.4e-6 of the sum's magnitude, plain fp32 0.75e-6) at half the
+// matrix-core work, and far inside the 1e-4 forward tolerance of SURVEY 8(d).  (The reference itself runs these
+// convolutions in TF32 -- 10 significant bits -- on the GPUs it was written for: torch.backends.cudnn.allow_tf32.)
+// DPC_CONV_MODE=x6 selects the bf16x6 kernels, DPC_CONV_MODE=f32 the native fp32 MFMA.
+//
+// Data flow = conv3x6.hip's pipelined direct-weight variant: a workgroup owns a 4x4x8 output tile; per 16-channel chunk
+// the 6x6x10 halo is staged once in LDS already split into the two fp16 planes (80 B per point: 2 x 32 B + 16 B pad =>
+// conflict-free ds_read_b128 with the pitch-12 / lane_hw layout), the 27 taps are LDS offsets, and the pre-split weights
+// ([tap][chunk][n][2 planes][16] fp16) stream from L2 into a 3-deep register ring two taps ahead.  The epilogue rescales
+// by 2^-16, adds the bias and emits the GroupNorm partial sums; the halo staging optionally applies the producer's
+// GroupNorm + (scale, shift) + SiLU (see Conv3hParams).
+// Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:192).
+#include "common.h"
+
+namespace dpc {
+
+namespace f3 {
+constexpr int TF = 4, TH = 4, TW = 8;
+constexpr int HF = TF + 2, HH = TH + 2, HWL = TW + 2, HWD = 12;
+constexpr int NLOG = HF * HH * HWL;        // 360 halo points
+constexpr int NSLOT = HF * HH * HWD;       // 432 LDS slots
+constexpr int KC = 16;
+constexpr int PST = 80;                    // bytes per halo point in LDS (2 planes x 32 B + 16 pad; 5 x 16 B: odd)
+constexpr int WROW = 64;                   // bytes per output channel per (tap, chunk) in the packed weights
+constexpr int HLOADS = (NLOG * 4 + 255) / 256;
+constexpr float SA = 16.0f, SW = 4096.0f, DESCALE = 1.0f / 65536.0f;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lane_hw(int i, int& h, int& w) {      // see conv3h.hip
+    if (i < 4) { h = 0; w = i; }
+    else if (i < 12) { h = 1; w = i - 4; }
+    else if (i < 16) { h = 0; w = i - 8; }
+    else if (i < 20) { h = 3; w = i - 16; }
+    else if (i < 28) { h = 2; w = i - 20; }
+    else { h = 3; w = i - 24; }
+}
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+
+// 4 floats (already scaled) -> two (2 x u32) packs of 4 fp16 each: h1 = fp16(x), h2 = fp16(x - h1)
+__device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
+    const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
+    p1.x = cvt_pk_f16(x0, x1);
+    p1.y = cvt_pk_f16(x2, x3);
+    const f16x2 a = __builtin_bit_cast(f16x2, p1.x), b = __builtin_bit_cast(f16x2, p1.y);
+    p2.x = cvt_pk_f16(x0 - (float)a.x, x1 - (float)a.y);
+    p2.y = cvt_pk_f16(x2 - (float)b.x, x3 - (float)b.y);
+}
+}  // namespace f3
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
+    using namespace f3;
+    constexpr int NT = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
+    unsigned char* halo = smem_f3;                      // [NSLOT][PST]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / BN;
+    const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH - 1) / TH, ntw = (p.W + TW - 1) / TW;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: consecutive tiles (shared halo planes, same weights) land on the same XCD's L2
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n0 = (bid % ntn) * BN;
+    int t = bid / ntn;
+    const int w0 = (t % ntw) * TW; t /= ntw;
+    const int h0 = (t % nth) * TH; t /= nth;
+    const int f0 = (t % ntf) * TF;
+    const int b = t / ntf;
+    const int K = p.C0 + p.C1;
+
+    long long hoff[HLOADS];
+    bool hok[HLOADS];
+    int hdst[HLOADS];
+#pragma unroll
+    for (int i = 0; i < HLOADS; ++i) {
+        const int q = tid + 256 * i;
+        const int pt = q >> 2;
+        const int pf = pt / (HH * HWL), ph = (pt / HWL) % HH, pw = pt % HWL;
+        const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
+        hok[i] = pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        hoff[i] = (((long long)b * p.F + f) * p.H + h) * p.W + w;
+        hdst[i] = ((pt / HWL) * HWD + pt % HWL) * PST + (q & 3) * 8;      // + plane*32
+    }
+    const int hslot = (tid & 3) * 4;
+
+    f32x4 hreg[HLOADS];
+    auto load_halo = [&](int kc) {
+        const int c = kc * KC + hslot;
+        const float* src;
+        int cs, cc;
+        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        else { src = p.a1; cs = p.C1; cc = c - p.C0; }
+        const bool cok = c < K;
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && hok[i] && !(p.dbg & 2)) v = *reinterpret_cast<const f32x4*>(src + hoff[i] * cs + cc);
+            hreg[i] = v;
+        }
+    };
+    auto store_halo = [&](int kc) {
+        if (p.in_coef) {
+            // fused GroupNorm -> (scale + 1, shift) -> SiLU of the producer (Block.forward, ...conv3d.py:196-204); the zero
+            // padding of the convolution applies to the ACTIVATED tensor, so out-of-range points stay 0
+            const int c = kc * KC + hslot;
+            if (c < K) {
+                const f32x4* cf = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b * (K >> 2) + (c >> 2)) * 5;
+                const f32x4 mu = cf[0], ga = cf[1], be = cf[2], sc = cf[3], sh = cf[4];
+#pragma unroll
+                for (int i = 0; i < HLOADS; ++i) {
+                    if (hok[i]) {
+                        f32x4 y = (hreg[i] - mu) * ga + be;
+                        y = y * sc + sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
+                        hreg[i] = y;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            if (tid + 256 * i < NLOG * 4) {
+                uint2 p1, p2;
+                split2(hreg[i] * SA, p1, p2);
+                *reinterpret_cast<uint2*>(halo + hdst[i]) = p1;
+                *reinterpret_cast<uint2*>(halo + hdst[i] + 32) = p2;
+            }
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    const int a_lane = (((wm * 2) * HH + lh) * HWD + lw) * PST + hh * 16;
+
+    // weight fragments straight from L2/L1 into a 3-deep register ring (TWO taps ahead; 27 % 3 == 0 keeps the ring index
+    // static across channel chunks), A fragments double-buffered one tap ahead, the 27 taps fully unrolled (tap offsets are
+    // ds_read immediates), the 3 split-product MFMAs of the 2*NT accumulators issued round-robin.
+    const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
+                                 ((long long)n0 + wn * (BN / 2) + l31) * WROW + hh * 16;
+    f16x8 w[3][NT][2];
+    f16x8 a[2][2][2];
+    auto ldw = [&](int tap, int kc, f16x8 (&dst)[NT][2]) {
+        const unsigned char* src = wlane + ((p.dbg & 4) ? 0ll : ((long long)tap * p.kchunks + kc) * p.Npad * WROW);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) dst[nt][pl] = *reinterpret_cast<const f16x8*>(src + nt * 32 * WROW + pl * 32);
+    };
+    auto lda = [&](int tap, f16x8 (&dst)[2][2]) {
+        const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                dst[mt][pl] = *reinterpret_cast<const f16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
+    };
+    load_halo(0);
+    ldw(0, 0, w[0]);
+    if (p.kchunks > 0) ldw(1, 0, w[1]);
+    store_halo(0);
+    __syncthreads();
+    lda(0, a[0]);
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+        const bool more_kc = kc + 1 < p.kchunks;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int t2 = tap + 2;
+            if (t2 < 27) ldw(t2, kc, w[t2 % 3]);
+            else if (more_kc) ldw(t2 - 27, kc + 1, w[t2 % 3]);
+            if (tap == 0 && more_kc) load_halo(kc + 1);
+            if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+            asm volatile("" ::: "memory");      // pin the prefetches HERE (the scheduler otherwise sinks them to their use)
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};     // small terms first
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap & 1][mt][PA[term]], w[tap % 3][nt][PB[term]],
+                                                                             acc[mt][nt], 0, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+        if (more_kc) {
+            __syncthreads();
+            store_halo(kc + 1);
+            __syncthreads();
+            lda(0, a[0]);
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
+        const bool nok = n < p.N;
+        const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int f = f0 + wm * 2 + mt;
+            if (f >= p.F) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                int ih, iw;
+                lane_hw(i, ih, iw);
+                const int h = h0 + ih, w_ = w0 + iw;
+                if (nok && h < p.H && w_ < p.W && (!(p.dbg & 1) || acc[mt][nt][r] == 1.2345f)) {
+                    const float v = acc[mt][nt][r] * DESCALE + bv;
+                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w_) * p.N + n] = v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+        }
+        if (p.gn_part) {
+            // GroupNorm statistics of the OUTPUT: this wave's 2 frames x 32 points of column n (fixed summation order)
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (hh == 0 && nok) {
+                const long long tile = ((long long)(f0 / TF) * nth + h0 / TH) * ntw + w0 / TW;
+                float* dst = p.gn_part + ((((long long)b * ((long long)ntf * nth * ntw) + tile) * 2 + wm) * p.N + n) * 2;
+                dst[0] = ssum;
+                dst[1] = ssq;
+            }
+        }
+    }
+}
+
+int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
+    using namespace f3;
+    DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv3f3: channel counts must be multiples of 4");
+    DPC_REQUIRE(p.kchunks == (p.C0 + p.C1 + KC - 1) / KC, "conv3f3: kchunks mismatch");
+    DPC_REQUIRE(!(p.in_coef && p.C1 != 0), "conv3f3: fused input normalisation needs a single source");
+    if (p.B == 0) return DPC_OK;
+    const long long tiles = (long long)p.B * ((p.F + TF - 1) / TF) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const double M = (double)p.B * p.F * p.H * p.W;
+    const double flops = 2.0 * M * p.N * 27.0 * (p.C0 + p.C1);
+    const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
+    const bool wide = p.Npad % 128 == 0 && p.N > 64;
+    static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
+    Conv3hParams pd = p;
+    pd.dbg = dbg;
+    ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
+    const size_t lds = (size_t)NSLOT * PST;
+    if (wide) {
+        const long long grid = tiles * (p.Npad / 128);
+        DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
+        hipLaunchKernelGGL((conv3f3_kernel<128>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+    } else {
+        DPC_REQUIRE(p.Npad % 64 == 0, "conv3f3: Npad must be a multiple of 64");
+        const long long grid = tiles * (p.Npad / 64);
+        DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
+        hipLaunchKernelGGL((conv3f3_kernel<64>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+    }
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// ---- weight pre-split: reference [N][K][3][3][3] fp32 -> [27][kchunks][Npad][2 planes][16] fp16 (scaled by 2^12)
+__global__ void pack_weights_f3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int K,
+                                       int kchunks) {
+    const long long total = 27ll * kchunks * Npad * 16;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % 16);
+        long long r = i / 16;
+        const int n = (int)(r % Npad);
+        r /= Npad;
+        const int kc = (int)(r % kchunks);
+        const int tap = (int)(r / kchunks);
+        const int c = kc * 16 + kk;
+        float v = 0.f;
+        if (n < N && c < K) v = f3::sat16(w[((long long)n * K + c) * 27 + tap] * f3::SW);
+        const unsigned p1 = f3::cvt_pk_f16(v, 0.f) & 0xffffu;
+        const float h1 = (float)__builtin_bit_cast(f3::f16x2, p1).x;
+        const unsigned p2 = f3::cvt_pk_f16(v - h1, 0.f) & 0xffffu;
+        unsigned short* dst = wp + (((long long)tap * kchunks + kc) * Npad + n) * 32 + kk;
+        dst[0] = (unsigned short)p1;
+        dst[16] = (unsigned short)p2;
+    }
+}
+
+int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s) {
+    const int kchunks = (K + 15) / 16;
+    const long long total = 27ll * kchunks * Npad * 16;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weights_f3_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), N, Npad,
+                       K, kchunks);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+}  // namespace dpc

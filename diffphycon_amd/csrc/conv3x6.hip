@@ -852,8 +852,9 @@ long long conv3x6_tiles_per_sample(int F, int H, int W) {
 int conv_mode_default() {
     static const int mode = [] {
         const char* e = getenv("DPC_CONV_MODE");
-        if (e && (e[0] == 'f' || e[0] == 'F')) return 0;
-        return 1;
+        if (e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3') return 0;        // "f32"
+        if (e && (e[0] == 'x' || e[0] == 'X' || e[0] == 'b')) return 1;         // "x6" / "bf16x6"
+        return 2;                                                               // "f16x3" (default)
     }();
     return mode;
 }

@@ -20,9 +20,10 @@ struct dpc_unet3d_s {
     std::set<std::string> loaded;
     // tables
     int frames = 0;
-    dpc::DevBuf t_bias, t_cos, t_sin, t_freq;
+    dpc::DevBuf t_bias, t_bias32, t_cos, t_sin, t_freq;
     bool finalized = false;
     bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 selects the unfused reference composition (A/B tests)
+    bool attn_x6 = true;         // DPC_ATTN_MODE=f32: fused attention on the fp32 MFMA instead of bf16x6
     bool fused_gn = true;        // DPC_UNFUSED_GN=1: standalone GroupNorm passes (3 per norm) instead of the conv-fused form
     // debug taps
     bool taps_on = false;
@@ -31,6 +32,8 @@ struct dpc_unet3d_s {
 };
 
 namespace dpc {
+
+static int tattn_dbg() { static const int v = [] { const char* e = getenv("DPC_TATTN_DBG"); return e ? atoi(e) : 0; }(); return v; }
 
 static std::vector<std::string> expected_names(const dpc_unet3d_cfg& c, const std::vector<int>& dims) {
     std::vector<std::string> v;
@@ -124,6 +127,10 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
         if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, ntaps)))) return rc;
         return launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s);
     }
+    if (conv_mode_default() == 2) {
+        if ((rc = pc.wp3.alloc((size_t)27 * pc.kchunks * pc.Npad * 64))) return rc;
+        return launch_pack_weights_f3(w, pc.wp3.p, N, pc.Npad, K, s);
+    }
     if ((rc = pc.wp6.alloc((size_t)27 * pc.kchunks * pc.Npad * 96))) return rc;
     return launch_pack_weights_x6(w, pc.wp6.p, N, pc.Npad, K, s);
 }
@@ -156,13 +163,17 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
              const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part,
              const float* in_coef) {
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
-    DPC_REQUIRE(!(gn_part || in_coef) || (pc.halo && conv_mode_default() == 1), "conv: GroupNorm fusion needs the conv3x6 path");
+    DPC_REQUIRE(!(gn_part || in_coef) || (pc.halo && conv_mode_default() >= 1), "conv: GroupNorm fusion needs the split-operand conv path");
     if (pc.halo) {
         DPC_REQUIRE(!resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo, "conv3h: plain 3x3x3 conv only");
         Conv3hParams q{};
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = pc.wp.f(); q.bias = bias; q.out = out;
         q.B = BF / F; q.F = F; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = pc.kchunks;
         q.gn_part = gn_part; q.in_coef = in_coef;
+        if (conv_mode_default() == 2) {
+            q.wp = reinterpret_cast<const float*>(pc.wp3.p);
+            return launch_conv3f3(q, s);
+        }
         if (conv_mode_default() == 1) {
             q.wp = reinterpret_cast<const float*>(pc.wp6.p);
             return launch_conv3x6(q, s);
@@ -198,6 +209,11 @@ struct Runner {
         auto it = h->raw.find(n);
         if (it == h->raw.end()) { rc = fail(DPC_ERR_STATE, "missing parameter " + n); return nullptr; }
         return it->second->f();
+    }
+    const float* raw_opt(const std::string& n) {
+        if (dry()) return nullptr;
+        auto it = h->raw.find(n);
+        return it == h->raw.end() ? nullptr : it->second->f();
     }
     const PackedConv* conv(const std::string& n) {
         if (dry()) return nullptr;
@@ -245,7 +261,7 @@ struct Runner {
                                     2 * Cout, 1, 0, s));
         }
         const bool same = (C1 == 0 && C0 == Cout);
-        if (h->fused_gn && conv_mode_default() == 1) {
+        if (h->fused_gn && conv_mode_default() >= 1) {
             // GroupNorm fused around the two conv3x6 launches: statistics come out of the conv epilogues, block1's
             // normalise + scale/shift + SiLU is applied inside block2's halo load (h1 never exists in HBM in activated
             // form), only block2's normalise + SiLU (+ residual) is a separate streaming pass.
@@ -336,8 +352,13 @@ struct Runner {
             TattnParams tp{};
             tp.x = x; tp.out = x; tp.gamma = raw(p + ".fn.norm.gamma"); tp.wqkv = raw(p + ".fn.fn.fn.to_qkv.weight");
             tp.wout = raw(p + ".fn.fn.fn.to_out.weight"); tp.rot_cos = h->t_cos.f(); tp.rot_sin = h->t_sin.f();
-            tp.bias = h->t_bias.f(); tp.npix = (long long)mb * HWl; tp.HW = HWl; tp.F = F;
-            RUN(launch_tattn_fused(tp, C, s));
+            tp.bias = h->t_bias.f(); tp.bias32 = h->t_bias32.f(); tp.dbg = tattn_dbg(); tp.npix = (long long)mb * HWl; tp.HW = HWl; tp.F = F;
+            const float* q6 = raw_opt(p + ".fn.fn.fn.to_qkv.weight#x6");
+            const float* o6 = raw_opt(p + ".fn.fn.fn.to_out.weight#x6");
+            if (h->attn_x6 && q6 && o6)
+                RUN(launch_tattn6(tp, reinterpret_cast<const unsigned char*>(q6), reinterpret_cast<const unsigned char*>(o6), C, s));
+            else
+                RUN(launch_tattn_fused(tp, C, s));
             return;
         }
         const size_t m = ar.mark();
@@ -500,6 +521,7 @@ int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out) {
     auto* h = new dpc_unet3d_s();
     h->cfg = *cfg;
     if (const char* e = getenv("DPC_UNFUSED_ATTN")) h->fused_attn = !(e[0] == '1');
+    if (const char* e = getenv("DPC_ATTN_MODE")) h->attn_x6 = !(e[0] == 'f' || e[0] == 'F');
     if (const char* e = getenv("DPC_UNFUSED_GN")) h->fused_gn = !(e[0] == '1');
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
@@ -562,6 +584,16 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
         if (!rc && (rc = b->alloc((size_t)numel * sizeof(float)))) return rc;
         DPC_HIP(hipMemcpyAsync(b->p, w, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
         h->raw[name] = std::move(b);
+        // pre-split per-head images for the bf16x6 fused attention kernels (inner dim 4 heads x 32)
+        const bool is_out = ends_with(name, "to_out.weight");
+        const int C = is_out ? (int)shape[0] : (int)shape[1];
+        const int inner = is_out ? (int)shape[1] : (int)shape[0] / 3;
+        if (!rc && inner == 128 && (C == 64 || C == 128)) {
+            auto b6 = std::make_unique<DevBuf>();
+            if ((rc = b6->alloc(is_out ? attn6_out_bytes(C) : attn6_qkv_bytes(C)))) return rc;
+            rc = launch_pack_attn6(w, reinterpret_cast<unsigned char*>(b6->p), C, is_out, s);
+            h->raw[name + "#x6"] = std::move(b6);
+        }
     } else {
         auto b = std::make_unique<DevBuf>();
         if ((rc = b->alloc((size_t)numel * sizeof(float)))) return rc;
@@ -587,6 +619,13 @@ int dpc_unet3d_set_tables(dpc_unet3d_t h, int frames, const float* bias, const f
     DPC_HIP(hipMemcpyAsync(h->t_cos.p, rc_, h->t_cos.bytes, hipMemcpyDeviceToDevice, s));
     DPC_HIP(hipMemcpyAsync(h->t_sin.p, rs_, h->t_sin.bytes, hipMemcpyDeviceToDevice, s));
     DPC_HIP(hipMemcpyAsync(h->t_freq.p, freqs, h->t_freq.bytes, hipMemcpyDeviceToDevice, s));
+    if (heads == 4 && frames <= 32) {
+        if ((rc = h->t_bias32.alloc((size_t)4 * 32 * 32 * 4))) return rc;
+        DPC_HIP(hipMemsetAsync(h->t_bias32.p, 0, h->t_bias32.bytes, s));
+        for (int hd = 0; hd < 4; ++hd)
+            DPC_HIP(hipMemcpy2DAsync(h->t_bias32.f() + hd * 1024, 32 * 4, bias + (size_t)hd * frames * frames, (size_t)frames * 4,
+                                     (size_t)frames * 4, frames, hipMemcpyDeviceToDevice, s));
+    }
     h->frames = frames;
     return DPC_OK;
 }
