@@ -107,7 +107,7 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
         if (rc) return rc;
         return launch_conv3h(q, s);
     }
-    const bool x6 = igemm_mode_default() == 1;
+    const bool x6 = igemm_mode_default() >= 1;
     int rc = x6 ? launch_pack_weights_g6(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s)
                 : launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s);
     if (rc) return rc;
@@ -140,7 +140,7 @@ int dpc_convtranspose3d_144_cl(const float* x_cl, const float* w_ref, const floa
                     off[t] = kh_[a][u] * 4 + kh_[b][v];
                 }
             p.N = Cout; p.Npad = igemm_npad(Cout); p.kchunks = igemm_kchunks(Cin); p.ntaps = 4;
-            const bool x6 = igemm_mode_default() == 1;
+            const bool x6 = igemm_mode_default() >= 1;
             int rc = x6 ? launch_pack_weights_g6(w_ref, wp, Cout, p.Npad, Cin, 4, 16, (long long)Cout * 16, off, s)
                         : launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, 4, 16, (long long)Cout * 16, off, s);
             if (rc) return rc;

@@ -10,6 +10,10 @@
 //    4-bank groups, so the ds_read_b128 fragment reads are conflict-free), double buffered.
 // B: weights pre-split at load time into [iteration][n][3 planes][32 k] bf16 and read as fragments straight from L2/L1
 //    into registers one iteration ahead (no LDS, no extra barrier).
+//
+// igemm3_kernel (default, DPC_IGEMM_MODE=f16x3) is the same kernel with the 2-way fp16 operand split of conv3f3.hip:
+// 22-bit operands pre-scaled by 2^4 / 2^12, three partial products per product, A rows of 2 planes x 32 k fp16 = 128 B
+// + 16 B pad (144 B = 9 x 16 B), weights [iteration][n][2 planes][32 k] fp16, epilogue rescale by 2^-16.
 #include "common.h"
 
 namespace dpc {
@@ -217,15 +221,218 @@ __global__ __launch_bounds__(256, 2) void igemm6_kernel(IgemmParams p, const uns
     }
 }
 
+namespace g3 {
+constexpr int BM = 128, BK = 32;
+constexpr int RS = 144;                     // LDS bytes per A row (2 planes x 64 B + 16 pad)
+constexpr int WROW = 128;                   // packed weight bytes per output channel per iteration
+constexpr float SA = 16.0f, SW = 4096.0f, DESCALE = 1.0f / 65536.0f;
+typedef _Float16 f16x2_g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+__device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
+    const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
+    p1.x = cvt_pk_f16(x0, x1);
+    p1.y = cvt_pk_f16(x2, x3);
+    const f16x2_g a = __builtin_bit_cast(f16x2_g, p1.x), b = __builtin_bit_cast(f16x2_g, p1.y);
+    p2.x = cvt_pk_f16(x0 - (float)a.x, x1 - (float)a.y);
+    p2.y = cvt_pk_f16(x2 - (float)b.x, x3 - (float)b.y);
+}
+}  // namespace g3
+
+typedef _Float16 f16x8_g __attribute__((ext_vector_type(8)));
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm3_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+    using namespace g3;
+    constexpr int NT = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    unsigned char* As0 = smem3;
+    unsigned char* As1 = As0 + BM * RS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / BN;
+    const int mtiles = (int)((p.M + BM - 1) / BM);
+    int bid = blockIdx.x;
+    {
+        const int nb = mtiles * ntn, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long m0 = (long long)(bid / ntn) * BM;
+    const int n0 = (bid % ntn) * BN;
+
+    // ---- per-thread A rows: 4 rows (tid/8 + 32 i), one float4 column (tid%8)*4   (identical to igemm.hip)
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int HoWo = p.Ho * p.Wo;
+    int r_bf[4], r_f[4], r_h[4], r_w[4];
+    bool r_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long m = m0 + arow + 32 * i;
+        r_ok[i] = m < p.M;
+        const long long mm = r_ok[i] ? m : 0;
+        const int bf = (int)(mm / HoWo);
+        const int hw = (int)(mm - (long long)bf * HoWo);
+        const int ho = hw / p.Wo;
+        r_bf[i] = bf;
+        r_f[i] = bf % p.F;
+        r_h[i] = ho * p.sh;
+        r_w[i] = (hw - ho * p.Wo) * p.sw;
+    }
+    const int K = p.C0 + p.C1;
+    f32x4 ra[4];
+    long long roff[4];
+    bool rvalid[4];
+    int cur_tap = -1;
+    auto load_a = [&](int it) {
+        const int tap = it / p.kchunks, kc = it - tap * p.kchunks;
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            const int df = p.tdf[tap], dh = p.tdh[tap], dw = p.tdw[tap];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int fi = r_f[i] + df, hi = r_h[i] + dh, wi = r_w[i] + dw;
+                rvalid[i] = r_ok[i] && (unsigned)fi < (unsigned)p.F && (unsigned)hi < (unsigned)p.Hi &&
+                            (unsigned)wi < (unsigned)p.Wi;
+                roff[i] = ((long long)(r_bf[i] + df) * p.Hi + hi) * p.Wi + wi;
+            }
+        }
+        const int c = kc * BK + acol;
+        const float* src;
+        int cs, cc;
+        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        else { src = p.a1; cs = p.C1; cc = c - p.C0; }
+        const bool cok = c < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && rvalid[i]) {
+                v = *reinterpret_cast<const f32x4*>(src + roff[i] * cs + cc);
+                if (p.ln_stats) {
+                    const float mean = p.ln_stats[2 * roff[i]], inv = p.ln_stats[2 * roff[i] + 1];
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + c);
+                    v = (v - mean) * inv * g;
+                }
+            }
+            ra[i] = v;
+        }
+    };
+    auto store_a = [&](unsigned char* As) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 p1, p2;
+            split2(ra[i] * SA, p1, p2);
+            unsigned char* dst = As + (arow + 32 * i) * RS + acol * 2;
+            *reinterpret_cast<uint2*>(dst) = p1;
+            *reinterpret_cast<uint2*>(dst + 64) = p2;
+        }
+    };
+    // weight fragments: [it][Npad][2][32] fp16 = 128 B per n; lane (n = l31, half hh) reads 8 k = 16 B per plane and k16 step
+    const unsigned char* wlane = wp6 + ((long long)n0 + wn * (BN / 2) + l31) * WROW + hh * 16;
+    f16x8_g wc[2][NT][2], wx[2][NT][2];
+    auto ldw = [&](int it, f16x8_g (&w)[2][NT][2]) {
+        const unsigned char* src = wlane + (long long)it * p.Npad * WROW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    w[ks][nt][pl] = *reinterpret_cast<const f16x8_g*>(src + nt * 32 * WROW + pl * 64 + ks * 32);
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int a_lane = (wm * 64 + l31) * RS + hh * 16;
+    const int niter = p.ntaps * p.kchunks;
+    load_a(0);
+    ldw(0, wc);
+    store_a(As0);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const bool more = it + 1 < niter;
+        if (more) { load_a(it + 1); ldw(it + 1, wx); }
+        const unsigned char* As = (it & 1) ? As1 : As0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8_g a[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    a[mt][pl] = *reinterpret_cast<const f16x8_g*>(As + a_lane + mt * 32 * RS + pl * 64 + ks * 32);
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};     // small terms first
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], wc[ks][nt][PB[term]], acc[mt][nt], 0, 0, 0);
+        }
+        if (more) {
+            store_a((it & 1) ? As0 : As1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) wc[ks][nt][pl] = wx[ks][nt][pl];
+        }
+        __syncthreads();
+    }
+    // ---- epilogue (same accumulator layout and output modes as igemm.hip)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][r] * DESCALE + bv;
+                if (p.resid) v += p.resid[m * p.N + n];
+                long long o;
+                if (p.out_mode == 0) {
+                    o = m * p.N + n;
+                } else if (p.out_mode == 1) {
+                    const long long bf = m / HoWo, hw = m - bf * HoWo;
+                    o = (bf * p.N + n) * (long long)HoWo + hw;
+                } else {
+                    const long long bf = m / HoWo;
+                    const int hw = (int)(m - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
+                    o = ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N + n;
+                }
+                p.out[o] = v;
+            }
+        }
+    }
+}
+
 int igemm_mode_default() {
     static const int mode = [] {
         const char* e = getenv("DPC_IGEMM_MODE");
-        if (e && (e[0] == 'f' || e[0] == 'F')) return 0;      // native fp32 MFMA (igemm.hip)
-        return 1;                                              // bf16x6
+        if (e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3') return 0;      // "f32": native fp32 MFMA (igemm.hip)
+        if (e && (e[0] == 'x' || e[0] == 'X' || e[0] == 'b')) return 1;       // "x6": bf16x6
+        return 2;                                                             // "f16x3" (default)
     }();
     return mode;
 }
 
+// sized for the larger (bf16x6) layout; the f16x3 layout uses 128 of the 192 bytes per (iteration, n)
 size_t igemm6_packed_bytes(int Npad, int K, int ntaps) { return (size_t)ntaps * igemm_kchunks(K) * Npad * 192; }
 
 int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
@@ -244,6 +451,17 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
     // so that the launch still covers the 256 CUs at least twice
     const bool wide = p.Npad % 128 == 0 && p.N > 64 && (long long)mtiles * (p.Npad / 128) >= 512;
     ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
+    if (igemm_mode_default() == 2) {
+        const size_t lds3 = 2 * (size_t)g3::BM * g3::RS;
+        if (wide) {
+            hipLaunchKernelGGL(igemm3_kernel<128>, dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
+        } else {
+            DPC_REQUIRE(p.Npad % 64 == 0, "igemm3: Npad must be a multiple of 64");
+            hipLaunchKernelGGL(igemm3_kernel<64>, dim3(mtiles * (p.Npad / 64)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
+        }
+        DPC_LAUNCH_CHECK();
+        return DPC_OK;
+    }
     const size_t lds = 2 * (size_t)BM * RS;
     if (wide) {
         hipLaunchKernelGGL(igemm6_kernel<128>, dim3(mtiles * (p.Npad / 128)), dim3(256), lds, s, p, (const unsigned char*)wp6);
@@ -258,7 +476,7 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
 // ---- weight pre-split: wp6[it = tap*kchunks + kc][n][plane][kk] (bf16) from w[n*stride_n + c*stride_c + tap_off[tap]]
 struct PackTaps6 { int off[32]; };
 __global__ void pack_weights_g6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int K,
-                                       int kchunks, int ntaps, long long stride_n, long long stride_c, PackTaps6 t) {
+                                       int kchunks, int ntaps, long long stride_n, long long stride_c, PackTaps6 t, int f16x3) {
     const long long total = (long long)ntaps * kchunks * Npad * 32;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 32);
@@ -270,6 +488,15 @@ __global__ void pack_weights_g6_kernel(const float* __restrict__ w, unsigned sho
         const int c = kc * 32 + kk;
         float v = 0.f;
         if (n < N && c < K) v = w[n * stride_n + c * stride_c + t.off[tap]];
+        if (f16x3) {
+            v = g3::sat16(v * g3::SW);
+            const unsigned h1 = g3::cvt_pk_f16(v, 0.f) & 0xffffu;
+            const unsigned h2 = g3::cvt_pk_f16(v - (float)__builtin_bit_cast(g3::f16x2_g, h1).x, 0.f) & 0xffffu;
+            unsigned short* d3 = wp + (((long long)tap * kchunks + kc) * Npad + n) * 64 + kk;
+            d3[0] = (unsigned short)h1;
+            d3[32] = (unsigned short)h2;
+            continue;
+        }
         const unsigned p1 = g6::cvt_pk_bf16(v, 0.f) & 0xffffu;
         const float r1 = v - __uint_as_float(p1 << 16);
         const unsigned p2 = g6::cvt_pk_bf16(r1, 0.f) & 0xffffu;
@@ -291,7 +518,7 @@ int launch_pack_weights_g6(const float* w, void* wp6, int N, int Npad, int K, in
     const long long total = (long long)ntaps * kchunks * Npad * 32;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_g6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad,
-                       K, kchunks, ntaps, stride_n, stride_c, t);
+                       K, kchunks, ntaps, stride_n, stride_c, t, igemm_mode_default() == 2 ? 1 : 0);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -123,7 +123,7 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     rc = launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s, bk);
     if (rc) return rc;
     if (!pc.halo) {
-        if (igemm_mode_default() != 1) return DPC_OK;
+        if (igemm_mode_default() == 0) return DPC_OK;
         if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, ntaps)))) return rc;
         return launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s);
     }
@@ -153,7 +153,7 @@ int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b
     int rc = pc.wp.alloc((size_t)4 * pc.kchunks * pc.Npad * 32 * sizeof(float));
     if (rc) return rc;
     if ((rc = launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, 4, 16, (long long)N * 16, off, s))) return rc;
-    if (igemm_mode_default() != 1) return DPC_OK;
+    if (igemm_mode_default() == 0) return DPC_OK;
     if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, 4)))) return rc;
     return launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, 4, 16, (long long)N * 16, off, s);
 }
