@@ -24,14 +24,11 @@
 namespace dpc {
 
 namespace f3 {
-constexpr int TF = 4, TH = 4, TW = 8;
-constexpr int HF = TF + 2, HH = TH + 2, HWL = TW + 2, HWD = 12;
-constexpr int NLOG = HF * HH * HWL;        // 360 halo points
-constexpr int NSLOT = HF * HH * HWD;       // 432 LDS slots
+constexpr int TH = 4, TW = 8;
+constexpr int HH = TH + 2, HWL = TW + 2, HWD = 12;
 constexpr int KC = 16;
 constexpr int PST = 80;                    // bytes per halo point in LDS (2 planes x 32 B + 16 pad; 5 x 16 B: odd)
 constexpr int WROW = 64;                   // bytes per output channel per (tap, chunk) in the packed weights
-constexpr int HLOADS = (NLOG * 4 + 255) / 256;
 constexpr float SA = 16.0f, SW = 4096.0f, DESCALE = 1.0f / 65536.0f;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -64,15 +61,24 @@ __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
 }
 }  // namespace f3
 
-template <int BN>
+// WM x WN waves (WM * WN = 4): wave (wm, wn) owns frames 2 wm, 2 wm + 1 of the tile (2 x 32 points) and BN / WN channels.
+// <64, 2> / <128, 2>: 4x4x8 tile, 2 x 2 waves.  <64, 4>: 8x4x8 tile, 4 x 1 waves -- every A fragment feeds both 32-channel
+// column tiles (half the LDS reads per MFMA of <64, 2>) and the prologue / epilogue are amortised over twice the work.
+// WR: weight ring depth (divides 27), AD: A-fragment ring depth (2 or 3).
+template <int BN, int WM, int WR, int AD>
 __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
+    static_assert(27 % WR == 0 && (AD == 2 || AD == 3), "static ring indices across channel chunks");
     using namespace f3;
-    constexpr int NT = BN / 64;
+    constexpr int WN = 4 / WM;
+    constexpr int NT = BN / (32 * WN);
+    constexpr int TF = 2 * WM, HF = TF + 2;
+    constexpr int NLOG = HF * HH * HWL;        // 360 / 600 halo points
+    constexpr int HLOADS = (NLOG * 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
     unsigned char* halo = smem_f3;                      // [NSLOT][PST]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hh = lane >> 5;
     const int ntn = p.Npad / BN;
     const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH - 1) / TH, ntw = (p.W + TW - 1) / TW;
     int bid = blockIdx.x;
@@ -161,13 +167,14 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
     lane_hw(l31, lh, lw);
     const int a_lane = (((wm * 2) * HH + lh) * HWD + lw) * PST + hh * 16;
 
-    // weight fragments straight from L2/L1 into a 3-deep register ring (TWO taps ahead; 27 % 3 == 0 keeps the ring index
-    // static across channel chunks), A fragments double-buffered one tap ahead, the 27 taps fully unrolled (tap offsets are
-    // ds_read immediates), the 3 split-product MFMAs of the 2*NT accumulators issued round-robin.
+    // weight fragments straight from L2/L1 into a WR-deep register ring (WR-1 taps ahead: at 3 MFMAs per product a tap
+    // lasts only 192 (BN = 64) / 384 cycles, so the 64-wide kernel runs 8 taps ahead to cover the L2 latency; 27 % WR == 0
+    // keeps the ring index static across channel chunks), A fragments AD-1 taps ahead, the 27 taps fully unrolled (tap
+    // offsets are ds_read immediates), the 3 split-product MFMAs of the 2*NT accumulators issued round-robin.
     const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
-                                 ((long long)n0 + wn * (BN / 2) + l31) * WROW + hh * 16;
-    f16x8 w[3][NT][2];
-    f16x8 a[2][2][2];
+                                 ((long long)n0 + wn * (BN / WN) + l31) * WROW + hh * 16;
+    f16x8 w[WR][NT][2];
+    f16x8 a[AD][2][2];
     auto ldw = [&](int tap, int kc, f16x8 (&dst)[NT][2]) {
         const unsigned char* src = wlane + ((p.dbg & 4) ? 0ll : ((long long)tap * p.kchunks + kc) * p.Npad * WROW);
 #pragma unroll
@@ -185,20 +192,21 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
                 dst[mt][pl] = *reinterpret_cast<const f16x8*>(halo + aoff + mt * (HH * HWD * PST) + pl * 32);
     };
     load_halo(0);
-    ldw(0, 0, w[0]);
-    if (p.kchunks > 0) ldw(1, 0, w[1]);
+#pragma unroll
+    for (int i = 0; i < WR - 1; ++i) ldw(i, 0, w[i]);
     store_halo(0);
     __syncthreads();
-    lda(0, a[0]);
+#pragma unroll
+    for (int i = 0; i < AD - 1; ++i) lda(i, a[i]);
     for (int kc = 0; kc < p.kchunks; ++kc) {
         const bool more_kc = kc + 1 < p.kchunks;
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            const int t2 = tap + 2;
-            if (t2 < 27) ldw(t2, kc, w[t2 % 3]);
-            else if (more_kc) ldw(t2 - 27, kc + 1, w[t2 % 3]);
+            const int tw = tap + WR - 1, ta = tap + AD - 1;
+            if (tw < 27) ldw(tw, kc, w[tw % WR]);
+            else if (more_kc) ldw(tw - 27, kc + 1, w[tw % WR]);
             if (tap == 0 && more_kc) load_halo(kc + 1);
-            if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+            if (ta < 27) lda(ta, a[ta % AD]);
             asm volatile("" ::: "memory");      // pin the prefetches HERE (the scheduler otherwise sinks them to their use)
             constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};     // small terms first
 #pragma unroll
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap & 1][mt][PA[term]], w[tap % 3][nt][PB[term]],
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap % AD][mt][PA[term]], w[tap % WR][nt][PB[term]],
                                                                              acc[mt][nt], 0, 0, 0);
             asm volatile("" ::: "memory");
         }
@@ -215,13 +223,14 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
             __syncthreads();
             store_halo(kc + 1);
             __syncthreads();
-            lda(0, a[0]);
+#pragma unroll
+            for (int i = 0; i < AD - 1; ++i) lda(i, a[i]);
         }
     }
 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
+        const int n = n0 + wn * (BN / WN) + nt * 32 + l31;
         const bool nok = n < p.N;
         const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
         float ssum = 0.f, ssq = 0.f;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
             ssq += __shfl_xor(ssq, 32, 64);
             if (hh == 0 && nok) {
                 const long long tile = ((long long)(f0 / TF) * nth + h0 / TH) * ntw + w0 / TW;
-                float* dst = p.gn_part + ((((long long)b * ((long long)ntf * nth * ntw) + tile) * 2 + wm) * p.N + n) * 2;
+                float* dst = p.gn_part + ((((long long)b * ((long long)ntf * nth * ntw) + tile) * WM + wm) * p.N + n) * 2;
                 dst[0] = ssum;
                 dst[1] = ssq;
             }
@@ -263,25 +272,30 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     DPC_REQUIRE(p.kchunks == (p.C0 + p.C1 + KC - 1) / KC, "conv3f3: kchunks mismatch");
     DPC_REQUIRE(!(p.in_coef && p.C1 != 0), "conv3f3: fused input normalisation needs a single source");
     if (p.B == 0) return DPC_OK;
-    const long long tiles = (long long)p.B * ((p.F + TF - 1) / TF) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const double M = (double)p.B * p.F * p.H * p.W;
     const double flops = 2.0 * M * p.N * 27.0 * (p.C0 + p.C1);
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
+    static const int tall_ok = [] { const char* e = getenv("DPC_CONV3F3_TALL"); return e ? atoi(e) : 1; }();
     Conv3hParams pd = p;
     pd.dbg = dbg;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
-    const size_t lds = (size_t)NSLOT * PST;
+    // the 8-frame tile keeps the GroupNorm partial-sum count of the 4-frame tiling (tiles x 2 == tiles8 x 4) iff F % 8 == 0
+    const bool tall = !wide && tall_ok && p.F % 8 == 0;
+    const int tf = tall ? 8 : 4;
+    const long long tiles = (long long)p.B * ((p.F + tf - 1) / tf) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    const size_t lds = (size_t)(tf + 2) * HH * HWD * PST;
     if (wide) {
         const long long grid = tiles * (p.Npad / 128);
         DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
-        hipLaunchKernelGGL((conv3f3_kernel<128>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        hipLaunchKernelGGL((conv3f3_kernel<128, 2, 3, 2>), dim3((unsigned)grid), dim3(256), lds, s, pd);
     } else {
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3f3: Npad must be a multiple of 64");
         const long long grid = tiles * (p.Npad / 64);
         DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
-        hipLaunchKernelGGL((conv3f3_kernel<64>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        if (tall) hipLaunchKernelGGL((conv3f3_kernel<64, 4, 3, 2>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        else hipLaunchKernelGGL((conv3f3_kernel<64, 2, 3, 2>), dim3((unsigned)grid), dim3(256), lds, s, pd);
     }
     DPC_LAUNCH_CHECK();
     return DPC_OK;

@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void tattn6_kernel(TattnPar
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                f32x4 v = {0.1f * l31, 0.2f, -0.3f, 0.01f * ks};
-                if (!(p.dbg & 16)) v = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4 * q);      // clamped address: always valid
+                f32x4 v = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4 * q);      // clamped address: always valid
                 if (!tok_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 xa[ks][q] = v;
                 s += (v.x + v.y) + (v.z + v.w);
@@ -128,10 +127,9 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void tattn6_kernel(TattnPar
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[nt][r] = 0.f;
 
-    const int dbg = p.dbg;
     for (int hd = 0; hd < 4; ++hd) {
         // ---- stage this head's pre-split weight images (block-cooperative verbatim copy)
-        if (!(dbg & 1) || hd == 0) {
+        {
             constexpr int NQ = QKV_BYTES / 4096, NO = OUT_BYTES / 4096;       // 16-byte pieces per thread
             const uint4* sq = reinterpret_cast<const uint4*>(wq6 + (size_t)hd * QKV_BYTES) + tid;
             const uint4* so = reinterpret_cast<const uint4*>(wo6 + (size_t)hd * OUT_BYTES) + tid;
@@ -145,8 +143,8 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void tattn6_kernel(TattnPar
             for (int q = 0; q < NQ; ++q) reinterpret_cast<uint4*>(Ws)[tid + q * 256] = tq[q];
 #pragma unroll
             for (int q = 0; q < NO; ++q) reinterpret_cast<uint4*>(Wo)[tid + q * 256] = to[q];
-            __syncthreads();
         }
+        __syncthreads();
 
         // ---- projections: Q^T, K^T (A = weights: lane = token, regs = head dims), V (A = x: lane = d, regs = token)
         f32x16 qT, kT, vv;
@@ -167,11 +165,8 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void tattn6_kernel(TattnPar
             const int ti = (FULL || l31 < F) ? l31 : 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                f32x4 c4 = {1.f, 1.f, 1.f, 1.f}, s4 = {0.5f, 0.5f, 0.5f, 0.5f};
-                if (!(dbg & 2)) {
-                    c4 = *reinterpret_cast<const f32x4*>(p.rot_cos + ti * 32 + 8 * jj + 4 * hh);
-                    s4 = *reinterpret_cast<const f32x4*>(p.rot_sin + ti * 32 + 8 * jj + 4 * hh);
-                }
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.rot_cos + ti * 32 + 8 * jj + 4 * hh);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.rot_sin + ti * 32 + 8 * jj + 4 * hh);
                 const float q0 = qT[4 * jj] * scale, q1 = qT[4 * jj + 1] * scale, q2 = qT[4 * jj + 2] * scale,
                             q3 = qT[4 * jj + 3] * scale;
                 qT[4 * jj] = __fadd_rn(__fmul_rn(q0, c4.x), __fmul_rn(-q1, s4.x));
@@ -200,8 +195,7 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void tattn6_kernel(TattnPar
         float m = -INFINITY;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {       // registers 4jj .. 4jj+3 = keys 8jj + 4hh .. +3: one 16-byte load of the padded table
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 2)) b4 = *reinterpret_cast<const f32x4*>(p.bias32 + (hd * 32 + l31) * 32 + 8 * jj + 4 * hh);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias32 + (hd * 32 + l31) * 32 + 8 * jj + 4 * hh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float sv = st[4 * jj + e] + b4[e];
@@ -255,12 +249,12 @@ __global__ __launch_bounds__(256, (C == 64 ? 2 : 1)) void tattn6_kernel(TattnPar
         for (int r = 0; r < 16; ++r) {           // residual loads first, unconditional (clamped token), then the stores
             const int i = rowmap6(r, hh);
             const int ic = (FULL || i < F) ? i : 0;
-            res[r] = (dbg & 4) ? 0.f : p.x[(row0 + (long long)ic * HW) * C + nt * 32 + l31];
+            res[r] = p.x[(row0 + (long long)ic * HW) * C + nt * 32 + l31];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = rowmap6(r, hh);
-            if (active && (FULL || i < F) && (!(dbg & 8) || y[nt][r] == 12345.f)) p.out[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] + res[r];
+            if (active && (FULL || i < F)) p.out[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] + res[r];
         }
     }
 }
