@@ -138,7 +138,6 @@ struct TattnParams {
     long long npix;         // B*HW sequences
     long long HW;
     int F;
-    int dbg;                // DPC_TATTN_DBG experiment bits (0 in production)
 };
 // Fused Residual(PreNorm(SpatialLinearAttention)) (lattn_fused.hip); weights in the reference layout
 struct LattnParams {
@@ -162,6 +161,12 @@ size_t attn6_qkv_bytes(int C);
 size_t attn6_out_bytes(int C);
 int launch_pack_attn6(const float* w, unsigned char* dst, int C, bool is_out, hipStream_t s);
 int launch_tattn6(const TattnParams& p, const unsigned char* wq6, const unsigned char* wo6, int C, hipStream_t s);
+// persistent weight-stationary f16x3 version for C = 64 (tattn3.hip)
+bool tattn3_supported(int C, int F, int heads);
+size_t tattn3_qkv_bytes();
+size_t tattn3_out_bytes();
+int launch_pack_tattn3(const float* w, unsigned char* dst, bool is_out, hipStream_t s);
+int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, hipStream_t s);
 
 // "gather" variant for the 7x7x7 stem on the reference-layout input [BF, C, H, W] (K = taps*C flattened)
 struct StemParams {

@@ -1,0 +1,61 @@
+// Split-operand fp16 helpers for register-resident operands (see conv3f3.hip for the arithmetic): a value x (pre-scaled
+// by a power of two into fp16's range) is written as h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) -- 22 significant bits --
+// and a product is  a1 b1 + (a1 b2 + a2 b1)  on v_mfma_f32_32x32x16_f16 with fp32 accumulation.
+#pragma once
+#include "common.h"
+
+namespace dpc {
+namespace h3 {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+
+// 8 floats (already scaled and inside +-65504) -> two f16x8 planes (plane 0 = leading term)
+__device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                       f16x8 (&o)[2]) {
+    uint4 a, b;
+    a.x = cvt_pk(v0, v1); a.y = cvt_pk(v2, v3); a.z = cvt_pk(v4, v5); a.w = cvt_pk(v6, v7);
+    const f16x2 h0 = __builtin_bit_cast(f16x2, a.x), h1 = __builtin_bit_cast(f16x2, a.y);
+    const f16x2 h2 = __builtin_bit_cast(f16x2, a.z), h3_ = __builtin_bit_cast(f16x2, a.w);
+    b.x = cvt_pk(v0 - (float)h0.x, v1 - (float)h0.y);
+    b.y = cvt_pk(v2 - (float)h1.x, v3 - (float)h1.y);
+    b.z = cvt_pk(v4 - (float)h2.x, v5 - (float)h2.y);
+    b.w = cvt_pk(v6 - (float)h3_.x, v7 - (float)h3_.y);
+    o[0] = __builtin_bit_cast(f16x8, a);
+    o[1] = __builtin_bit_cast(f16x8, b);
+}
+
+// the two k-steps of a 32x32 accumulator used as an MFMA operand: k-step s = registers 8s .. 8s+7 of every lane
+// (rows (i&3) + 8(i>>2) + 4hh + 16s, i = 0..7); any operand contracted against it must use the same k order.
+// `mul` folds the descale of the producing GEMM and the pre-scale of this operand; SAT clamps into fp16's range.
+template <bool SAT>
+__device__ __forceinline__ void split_acc(const f32x16& v, float mul, f16x8 (&o)[2][2]) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = SAT ? sat16(v[r] * mul) : v[r] * mul;
+    split8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], o[0]);
+    split8(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], o[1]);
+}
+
+__device__ __forceinline__ void mfma3(f32x16& acc, const f16x8 (&a)[2], const f16x8 (&b)[2]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// LDS image of a pre-split 32-row weight block: [kstep][plane 2][row 32][khalf 2][8 fp16] = 1 KB per (kstep, plane);
+// lane (row l31, khalf hh) reads 16 B at l31*32 + hh*16: a wave covers the KB contiguously (conflict-free ds_read_b128).
+__device__ __forceinline__ void load_w2(const unsigned char* base, int kstep, int loff, f16x8 (&w)[2]) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) w[pl] = *reinterpret_cast<const f16x8*>(base + (kstep * 2 + pl) * 1024 + loff);
+}
+
+}  // namespace h3
+}  // namespace dpc

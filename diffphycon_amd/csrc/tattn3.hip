@@ -1,0 +1,316 @@
+// Fused temporal attention block, persistent and weight-stationary, on the fp16 matrix cores with split operands (f16x3):
+//   y = x + to_out( softmax( (q*s) k^T + bias ) v ),  q,k,v = to_qkv(LayerNorm_c(x)),  rotary on q,k
+// Reference: video_diffusion_pytorch_conv3d.py:165-184 (LayerNorm/PreNorm), :276-352 (Attention), :382,394,442.
+//
+// Dataflow of tattn6.hip (one wave = one pixel = one 32-token sequence = one 32-row MFMA tile, every intermediate produced
+// in the register layout the next MFMA consumes, qkv never in HBM) with two changes that remove its stalls:
+//  * at C = 64 the pre-split weights of ALL four heads (to_qkv 96 KB + to_out 32 KB as 2 fp16 planes), the rotary tables and
+//    the relative-position bias fit the 160 KB LDS of a CU together.  One 512-thread workgroup per CU loads them once and
+//    its 8 waves then loop over pixels with no barrier and no weight traffic at all (tattn6 re-staged 48 KB per head per
+//    4 pixels behind two barriers: 30 % of its time), prefetching the next pixel's rows during the current one;
+//  * f16x3 arithmetic (conv3f3.hip): 3 MFMAs per product instead of 6 and a 2-way register split (3 VALU / element instead
+//    of 5.5).  Operand scales are powers of two chosen per tensor: LayerNorm output, q, k, v, o: 2^4; softmax numerators
+//    (<= 1): 2^10; weights: 2^12; every accumulator is rescaled exactly where it is consumed.
+#include "f16x3.h"
+
+namespace dpc {
+
+using namespace h3;
+
+namespace t3 {
+constexpr int C = 64, KS = C / 16, NTC = C / 32;
+constexpr int HEAD_QKV = 3 * KS * 2048;            // bytes per head: q | k | v, each KS x 2 planes x 1 KB
+constexpr int HEAD_OUT = NTC * 2 * 2048;           // bytes per head: NTC column tiles x 2 k-steps x 2 planes x 1 KB
+constexpr int QKV_ALL = 4 * HEAD_QKV, OUT_ALL = 4 * HEAD_OUT;
+constexpr int TS = 36;                             // padded row stride (floats) of the rotary / bias tables in LDS
+constexpr int OFF_COS = QKV_ALL + OUT_ALL, OFF_SIN = OFF_COS + 32 * TS * 4, OFF_BIAS = OFF_SIN + 32 * TS * 4;
+constexpr int LDS_BYTES = OFF_BIAS + 4 * 32 * TS * 4;          // 158720
+constexpr float SX = 16.f, SWGT = 4096.f;
+constexpr float PROJ_DESCALE = 1.f / (SX * SWGT);  // accumulator -> true value of a projection
+constexpr float SQK = 16.f, SP = 1024.f, SV = 16.f, SO = 16.f;
+}  // namespace t3
+
+size_t tattn3_qkv_bytes() { return t3::QKV_ALL; }
+size_t tattn3_out_bytes() { return t3::OUT_ALL; }
+
+// to_qkv.weight [384][64] -> [head][q|k|v][ks][plane][32 rows][2][8];  to_out.weight [64][128] -> [head][nt][s][plane][32][2][8]
+__global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int is_out, int total) {
+    using namespace t3;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one value = 2 planes
+    if (idx >= total) return;
+    const int i = idx & 7, hh = (idx >> 3) & 1, r = (idx >> 4) & 31;
+    int rest = idx >> 9;
+    float v;
+    long long o;
+    if (!is_out) {
+        const int ks = rest % KS; rest /= KS;
+        const int part = rest % 3, hd = rest / 3;
+        v = w[(long long)(part * 128 + hd * 32 + r) * C + 16 * ks + 8 * hh + i];
+        o = ((long long)((hd * 3 + part) * KS + ks) * 2) * 512 + r * 16 + hh * 8 + i;
+    } else {
+        const int s = rest & 1; rest >>= 1;
+        const int nt = rest % NTC, hd = rest / NTC;
+        const int d = 16 * s + 4 * hh + (i & 3) + 8 * (i >> 2);      // k order of an accumulator operand (f16x3.h)
+        v = w[(long long)(nt * 32 + r) * 128 + hd * 32 + d];
+        o = ((long long)((hd * NTC + nt) * 2 + s) * 2) * 512 + r * 16 + hh * 8 + i;
+    }
+    v = sat16(v * SWGT);
+    const unsigned p1 = cvt_pk(v, 0.f) & 0xffffu;
+    const unsigned p2 = cvt_pk(v - (float)__builtin_bit_cast(f16x2, p1).x, 0.f) & 0xffffu;
+    dst[o] = (unsigned short)p1;
+    dst[o + 512] = (unsigned short)p2;
+}
+
+int launch_pack_tattn3(const float* w, unsigned char* dst, bool is_out, hipStream_t s) {
+    using namespace t3;
+    const int total = is_out ? 4 * NTC * 2 * 512 : 4 * 3 * KS * 512;
+    hipLaunchKernelGGL(pack_tattn3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(dst),
+                       is_out ? 1 : 0, total);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+__device__ __forceinline__ int rowmap3(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+template <bool FULL>     // FULL: F == 32, no token masks
+__global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const unsigned char* __restrict__ wq3,
+                                                        const unsigned char* __restrict__ wo3) {
+    using namespace t3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int loff = l31 * 32 + hh * 16;
+    const int F = p.F;
+
+    // ---- one-time fill: weight images verbatim, rotary / bias tables with padded rows
+    for (int q = tid; q < QKV_ALL / 16; q += 512) reinterpret_cast<uint4*>(smem3)[q] = reinterpret_cast<const uint4*>(wq3)[q];
+    for (int q = tid; q < OUT_ALL / 16; q += 512)
+        reinterpret_cast<uint4*>(smem3 + QKV_ALL)[q] = reinterpret_cast<const uint4*>(wo3)[q];
+    {
+        float* cosL = reinterpret_cast<float*>(smem3 + OFF_COS);
+        float* sinL = reinterpret_cast<float*>(smem3 + OFF_SIN);
+        float* biasL = reinterpret_cast<float*>(smem3 + OFF_BIAS);
+        for (int q = tid; q < 32 * 32; q += 512) {
+            const int r = q >> 5, c = q & 31;
+            cosL[r * TS + c] = r < F ? p.rot_cos[r * 32 + c] : 1.f;
+            sinL[r * TS + c] = r < F ? p.rot_sin[r * 32 + c] : 0.f;
+        }
+        for (int q = tid; q < 4 * 32 * 32; q += 512) biasL[(q >> 5) * TS + (q & 31)] = p.bias32[q];
+    }
+    __syncthreads();
+
+    const long long HW = p.HW;
+    const long long nwaves = (long long)gridDim.x * 8;
+    long long gp = (long long)blockIdx.x * 8 + wave;
+    const float qscale = 0.17677669529663687f;
+    const bool tok = FULL || l31 < F;
+    const int ti = tok ? l31 : 0;
+    const unsigned char* cosL = smem3 + OFF_COS + (ti * TS + 4 * hh) * 4;
+    const unsigned char* sinL = smem3 + OFF_SIN + (ti * TS + 4 * hh) * 4;
+    const unsigned char* biasL = smem3 + OFF_BIAS + (l31 * TS + 4 * hh) * 4;
+
+    // rows of a pixel: token f at row0 + f*HW; lane (token l31, half hh) holds channels 16ks + 8hh .. +7 of k-step ks
+    auto row0_of = [&](long long g) {
+        const unsigned bq = (unsigned)g / (unsigned)HW;             // npix < 2^31 (checked by the launcher)
+        return (long long)bq * F * HW + (long long)((unsigned)g - bq * (unsigned)HW);
+    };
+    f32x4 xr[KS][2];
+    auto load_rows = [&](long long row0) {
+        const float* src = p.x + (row0 + (long long)ti * HW) * C + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xr[ks][q] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4 * q);
+    };
+    if (gp < p.npix) load_rows(row0_of(gp));
+
+    for (; gp < p.npix; gp += nwaves) {
+        const long long row0 = row0_of(gp);
+        // ---- LayerNorm over channels (lane pair), scale, split
+        f16x8 xs[KS][2];
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (!tok) xr[ks][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = xr[ks][q];
+                    s += (v.x + v.y) + (v.z + v.w);
+                }
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s / (float)C;
+            float q2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 d = xr[ks][q] - mean;
+                    q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+            q2 += __shfl_xor(q2, 32, 64);
+            const float inv = 1.0f / sqrtf(q2 / (float)C + 1e-5f);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f32x4 n[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
+                    n[q] = (xr[ks][q] - mean) * inv * g * SX;      // a masked token has x = mean = 0: stays exactly 0
+                }
+                split8(sat16(n[0].x), sat16(n[0].y), sat16(n[0].z), sat16(n[0].w), sat16(n[1].x), sat16(n[1].y),
+                       sat16(n[1].z), sat16(n[1].w), xs[ks]);
+            }
+        }
+        // ---- prefetch the next pixel's rows (consumed at the top of the next iteration)
+        if (gp + nwaves < p.npix) load_rows(row0_of(gp + nwaves));
+        asm volatile("" ::: "memory");
+
+        f32x16 y[NTC];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[nt][r] = 0.f;
+
+#pragma unroll 1
+        for (int hd = 0; hd < 4; ++hd) {
+            const unsigned char* Wq = smem3 + hd * HEAD_QKV;
+            const unsigned char* Wo = smem3 + QKV_ALL + hd * HEAD_OUT;
+            // ---- projections: Q^T, K^T (A = weights: lane = token, regs = head dims), V (A = x: lane = d, regs = token)
+            f32x16 qT, kT, vv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { qT[r] = 0.f; kT[r] = 0.f; vv[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f16x8 w[2];
+                load_w2(Wq, ks, loff, w);
+                mfma3(qT, w, xs[ks]);
+                load_w2(Wq + KS * 2048, ks, loff, w);
+                mfma3(kT, w, xs[ks]);
+                load_w2(Wq + 2 * KS * 2048, ks, loff, w);
+                mfma3(vv, xs[ks], w);
+            }
+            // ---- q * scale, rotary on q and k (pairs (2m, 2m+1) = registers (4jj, 4jj+1), (4jj+2, 4jj+3)); the results carry
+            //      the operand pre-scale SQK
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosL + 32 * jj);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinL + 32 * jj);
+                const float qm = qscale * (PROJ_DESCALE * SQK), km = PROJ_DESCALE * SQK;
+                const float q0 = qT[4 * jj] * qm, q1 = qT[4 * jj + 1] * qm, q2 = qT[4 * jj + 2] * qm, q3 = qT[4 * jj + 3] * qm;
+                qT[4 * jj] = __fadd_rn(__fmul_rn(q0, c4.x), __fmul_rn(-q1, s4.x));
+                qT[4 * jj + 1] = __fadd_rn(__fmul_rn(q1, c4.y), __fmul_rn(q0, s4.y));
+                qT[4 * jj + 2] = __fadd_rn(__fmul_rn(q2, c4.z), __fmul_rn(-q3, s4.z));
+                qT[4 * jj + 3] = __fadd_rn(__fmul_rn(q3, c4.w), __fmul_rn(q2, s4.w));
+                const float k0 = kT[4 * jj] * km, k1 = kT[4 * jj + 1] * km, k2 = kT[4 * jj + 2] * km, k3 = kT[4 * jj + 3] * km;
+                kT[4 * jj] = __fadd_rn(__fmul_rn(k0, c4.x), __fmul_rn(-k1, s4.x));
+                kT[4 * jj + 1] = __fadd_rn(__fmul_rn(k1, c4.y), __fmul_rn(k0, s4.y));
+                kT[4 * jj + 2] = __fadd_rn(__fmul_rn(k2, c4.z), __fmul_rn(-k3, s4.z));
+                kT[4 * jj + 3] = __fadd_rn(__fmul_rn(k3, c4.w), __fmul_rn(k2, s4.w));
+            }
+            // ---- S^T[j][i] = k_j . q_i   (A = K: lane = key j; B = Q: lane = query i; k index = head dim in register order)
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            {
+                f16x8 qs[2][2], kk[2][2];
+                split_acc<true>(qT, 1.f, qs);
+                split_acc<true>(kT, 1.f, kk);
+                mfma3(st, kk[0], qs[0]);
+                mfma3(st, kk[1], qs[1]);
+            }
+            // ---- bias + softmax over keys (lane-local + partner lane); registers 4jj .. 4jj+3 = keys 8jj + 4hh .. +3
+            float m = -INFINITY;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasL + (hd * 32 * TS + 8 * jj) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = st[4 * jj + e] * (1.f / (SQK * SQK)) + b4[e];
+                    if (!FULL && 8 * jj + 4 * hh + e >= F) sv = -INFINITY;
+                    st[4 * jj + e] = sv;
+                    m = fmaxf(m, sv);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(st[r] - m);
+                st[r] = e;
+                l += e;
+            }
+            l += __shfl_xor(l, 32, 64);
+            // ---- O^T[d][i] = sum_j V[j][d] P[i][j]   (A = V: lane = d; B = P: lane = query i; k index = key in register order)
+            f32x16 oT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+            {
+                f16x8 vs[2][2], ps[2][2];
+                split_acc<true>(vv, PROJ_DESCALE * SV, vs);
+                split_acc<false>(st, SP, ps);
+                mfma3(oT, vs[0], ps[0]);
+                mfma3(oT, vs[1], ps[1]);
+            }
+            // ---- Y[i][c] += sum_d O[i][d] Wout[c][hd*32+d]   (A = O: lane = token i; B = packed to_out slice); the softmax
+            //      normalisation, the descale of P and V and the pre-scale of O are one multiplier
+            {
+                f16x8 os[2][2];
+                split_acc<true>(oT, (SO / (SP * SV)) / l, os);
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f16x8 w[2];
+                        load_w2(Wo, nt * 2 + s, loff, w);
+                        mfma3(y[nt], os[s], w);
+                    }
+            }
+        }
+        // ---- residual + store (lane = channel, regs = token)
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {           // residual loads first, unconditional (clamped token), then the stores
+                const int i = rowmap3(r, hh);
+                const int ic = (FULL || i < F) ? i : 0;
+                res[r] = p.x[(row0 + (long long)ic * HW) * C + nt * 32 + l31];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rowmap3(r, hh);
+                if (FULL || i < F) p.out[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+            }
+        }
+    }
+}
+
+bool tattn3_supported(int C, int F, int heads) { return C == 64 && F <= 32 && heads == 4; }
+
+int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, hipStream_t s) {
+    using namespace t3;
+    DPC_REQUIRE(tattn3_supported(C, p.F, 4), "tattn3: unsupported shape");
+    DPC_REQUIRE(p.bias32, "tattn3: padded bias table missing");
+    if (p.npix == 0) return DPC_OK;
+    DPC_REQUIRE(p.npix < (1ll << 31), "tattn3: too many sequences for one launch");
+    const double rows = (double)p.npix * p.F;
+    ProfScope prof(PROF_TATTN_FUSED, 2.0 * rows * C * 384 + 4.0 * rows * p.F * 32 * 4 + 2.0 * rows * 128 * C,
+                   4.0 * rows * C * 2, s);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        DPC_HIP(hipGetDevice(&dev));
+        DPC_HIP(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount;
+        DPC_HIP(hipFuncSetAttribute((const void*)tattn3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)tattn3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    }
+    const long long grid = std::min<long long>((p.npix + 7) / 8, ncu);
+    if (p.F == 32) hipLaunchKernelGGL(tattn3_kernel<true>, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, wq3, wo3);
+    else hipLaunchKernelGGL(tattn3_kernel<false>, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, wq3, wo3);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+}  // namespace dpc

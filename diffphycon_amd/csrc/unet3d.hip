@@ -23,7 +23,7 @@ struct dpc_unet3d_s {
     dpc::DevBuf t_bias, t_bias32, t_cos, t_sin, t_freq;
     bool finalized = false;
     bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 selects the unfused reference composition (A/B tests)
-    bool attn_x6 = true;         // DPC_ATTN_MODE=f32: fused attention on the fp32 MFMA instead of bf16x6
+    int attn_mode = 2;           // DPC_ATTN_MODE = f32 (0: fused attention on the fp32 MFMA) | x6 (1: bf16x6) | f16x3 (2, default)
     bool fused_gn = true;        // DPC_UNFUSED_GN=1: standalone GroupNorm passes (3 per norm) instead of the conv-fused form
     // debug taps
     bool taps_on = false;
@@ -32,8 +32,6 @@ struct dpc_unet3d_s {
 };
 
 namespace dpc {
-
-static int tattn_dbg() { static const int v = [] { const char* e = getenv("DPC_TATTN_DBG"); return e ? atoi(e) : 0; }(); return v; }
 
 static std::vector<std::string> expected_names(const dpc_unet3d_cfg& c, const std::vector<int>& dims) {
     std::vector<std::string> v;
@@ -352,10 +350,14 @@ struct Runner {
             TattnParams tp{};
             tp.x = x; tp.out = x; tp.gamma = raw(p + ".fn.norm.gamma"); tp.wqkv = raw(p + ".fn.fn.fn.to_qkv.weight");
             tp.wout = raw(p + ".fn.fn.fn.to_out.weight"); tp.rot_cos = h->t_cos.f(); tp.rot_sin = h->t_sin.f();
-            tp.bias = h->t_bias.f(); tp.bias32 = h->t_bias32.f(); tp.dbg = tattn_dbg(); tp.npix = (long long)mb * HWl; tp.HW = HWl; tp.F = F;
+            tp.bias = h->t_bias.f(); tp.bias32 = h->t_bias32.f(); tp.npix = (long long)mb * HWl; tp.HW = HWl; tp.F = F;
             const float* q6 = raw_opt(p + ".fn.fn.fn.to_qkv.weight#x6");
             const float* o6 = raw_opt(p + ".fn.fn.fn.to_out.weight#x6");
-            if (h->attn_x6 && q6 && o6)
+            const float* q3 = raw_opt(p + ".fn.fn.fn.to_qkv.weight#h3");
+            const float* o3 = raw_opt(p + ".fn.fn.fn.to_out.weight#h3");
+            if (h->attn_mode == 2 && q3 && o3 && tattn3_supported(C, F, h->cfg.attn_heads))
+                RUN(launch_tattn3(tp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), C, s));
+            else if (h->attn_mode >= 1 && q6 && o6)
                 RUN(launch_tattn6(tp, reinterpret_cast<const unsigned char*>(q6), reinterpret_cast<const unsigned char*>(o6), C, s));
             else
                 RUN(launch_tattn_fused(tp, C, s));
@@ -521,7 +523,7 @@ int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out) {
     auto* h = new dpc_unet3d_s();
     h->cfg = *cfg;
     if (const char* e = getenv("DPC_UNFUSED_ATTN")) h->fused_attn = !(e[0] == '1');
-    if (const char* e = getenv("DPC_ATTN_MODE")) h->attn_x6 = !(e[0] == 'f' || e[0] == 'F');
+    if (const char* e = getenv("DPC_ATTN_MODE")) h->attn_mode = (e[0] == 'x' || e[0] == 'b') ? 1 : ((e[0] == 'f' && e[1] == '3') ? 0 : 2);
     if (const char* e = getenv("DPC_UNFUSED_GN")) h->fused_gn = !(e[0] == '1');
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
@@ -593,6 +595,12 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
             if ((rc = b6->alloc(is_out ? attn6_out_bytes(C) : attn6_qkv_bytes(C)))) return rc;
             rc = launch_pack_attn6(w, reinterpret_cast<unsigned char*>(b6->p), C, is_out, s);
             h->raw[name + "#x6"] = std::move(b6);
+        }
+        if (!rc && inner == 128 && C == 64 && name.find(".fn.fn.fn.") != std::string::npos) {     // temporal attention, C = 64
+            auto b3 = std::make_unique<DevBuf>();
+            if ((rc = b3->alloc(is_out ? tattn3_out_bytes() : tattn3_qkv_bytes()))) return rc;
+            rc = launch_pack_tattn3(w, reinterpret_cast<unsigned char*>(b3->p), is_out, s);
+            h->raw[name + "#h3"] = std::move(b3);
         }
     } else {
         auto b = std::make_unique<DevBuf>();
