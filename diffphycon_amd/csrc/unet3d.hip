@@ -311,6 +311,15 @@ struct Runner {
     void spatial_linear(const std::string& p, float* x, int C, int Hl, int Wl) {
         const long long P = (long long)mb * F * Hl * Wl;
         const int HD = h->cfg.attn_heads * 32;
+        if (h->fused_attn && h->attn_mode == 2 && lattn3_supported(C, h->cfg.attn_heads)) {
+            LattnParams lp{};
+            lp.x = x; lp.out = x; lp.gamma = raw(p + ".fn.norm.gamma"); lp.bout = raw(p + ".fn.fn.to_out.bias");
+            lp.images = (long long)mb * F; lp.N = Hl * Wl;
+            const float* q3 = raw(p + ".fn.fn.to_qkv.weight#h3");
+            const float* o3 = raw(p + ".fn.fn.to_out.weight#h3");
+            RUN(launch_lattn3(lp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), s));
+            return;
+        }
         if (h->fused_attn && lattn_fused_supported(C, h->cfg.attn_heads)) {
             const size_t m0 = ar.mark();
             LattnParams lp{};
@@ -596,7 +605,7 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
             rc = launch_pack_attn6(w, reinterpret_cast<unsigned char*>(b6->p), C, is_out, s);
             h->raw[name + "#x6"] = std::move(b6);
         }
-        if (!rc && inner == 128 && C == 64 && name.find(".fn.fn.fn.") != std::string::npos) {     // temporal attention, C = 64
+        if (!rc && inner == 128 && C == 64) {     // weight-stationary f16x3 attention kernels (tattn3.hip, lattn3.hip)
             auto b3 = std::make_unique<DevBuf>();
             if ((rc = b3->alloc(is_out ? tattn3_out_bytes() : tattn3_qkv_bytes()))) return rc;
             rc = launch_pack_tattn3(w, reinterpret_cast<unsigned char*>(b3->p), is_out, s);
