@@ -121,6 +121,7 @@ int launch_pack_weights_x6(const float* w, void* wp, int N, int Npad, int K, hip
 // same op with a 2-way fp16 split (22-bit operands, 3 MFMAs per product; conv3f3.hip); p.wp = [27][kchunks][Npad][2][16] fp16
 int launch_conv3f3(const Conv3hParams& p, hipStream_t s);
 int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
+long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad);     // GroupNorm partial-sum entries per (sample, channel)
 // 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6), 2: f16x3 split (conv3f3); env DPC_CONV_MODE=f32|x6|f16x3, default f16x3
 int conv_mode_default();
 

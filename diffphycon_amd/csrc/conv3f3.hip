@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
     f16x8 w[WR][NT][2];
     f16x8 a[AD][2][2];
     auto ldw = [&](int tap, int kc, f16x8 (&dst)[NT][2]) {
+        if ((p.dbg & 16) && (tap | kc)) return;                  // perf attribution: no weight traffic after the first tap
         const unsigned char* src = wlane + ((p.dbg & 4) ? 0ll : ((long long)tap * p.kchunks + kc) * p.Npad * WROW);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
             for (int pl = 0; pl < 2; ++pl) dst[nt][pl] = *reinterpret_cast<const f16x8*>(src + nt * 32 * WROW + pl * 32);
     };
     auto lda = [&](int tap, f16x8 (&dst)[2][2]) {
+        if ((p.dbg & 32) && tap) return;                         // perf attribution: no A-fragment LDS reads after tap 0
         const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
         const int aoff = a_lane + ((df * HH + dh) * HWD + dw) * PST;
 #pragma unroll
@@ -266,6 +268,280 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Big-tile variant (default where the shape allows): one 256-thread workgroup per CU, 512 registers per lane.
+// r01 attribution of the kernel above (DPC_CONV_DBG bits 16 / 32): streaming the weight fragments through the 64 B/clk
+// vector L1 costs 28 % of the launch at every shape -- at 3 MFMAs per product a wave retires a (2 x NT)-tile tap in
+// 192 NT cycles, so L1 runs at 2/3 of its bandwidth -- while the LDS A-fragment reads cost 4 %.  Here every wave owns a
+// 4 x 2 grid of 32x32 accumulators (4 point slabs x 64 channels, 128 accumulator registers): a weight fragment feeds
+// 4 slabs and an A fragment 2 column tiles, so per MFMA the L1 and the LDS traffic are both HALF of the (2 x 2) kernel's.
+//   BN = 64 : 4 x 1 waves over an 8 x 8 x 8 output tile  (halo 10 x 10 x 10, 96 KB)
+//   BN = 128: 2 x 2 waves over a  4 x 8 x 8 output tile  (halo  6 x 10 x 10, 57.6 KB)
+// A wave's slab mt is frame 2 wm + (mt >> 1), rows 4 (mt & 1) .. +3 of the tile.  With one workgroup per CU nothing else
+// hides the channel-chunk hand-over, so the GroupNorm/SiLU/split arithmetic of the NEXT chunk's halo runs in the middle
+// of the current chunk's taps (VALU co-issues with the MFMAs) and the hand-over is barrier, 16-byte LDS stores, barrier.
+namespace f3b {
+using namespace f3;
+constexpr int TH8 = 8, HH8 = TH8 + 2;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
+    using namespace f3b;
+    constexpr int WM = BN == 64 ? 4 : 2, WN = 4 / WM, MT = 4, NT = 2;
+    constexpr int TF = 2 * WM, HF = TF + 2;
+    constexpr int NLOG = HF * HH8 * HWL;               // 1000 / 600 halo points
+    constexpr int HLOADS = (NLOG * 4 + 255) / 256;     // 16 / 10
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3b[];
+    unsigned char* halo = smem_f3b;                    // [HF*HH8*HWD slots][PST]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / BN;
+    const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH8 - 1) / TH8, ntw = (p.W + TW - 1) / TW;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: consecutive tiles (shared halo planes, same weights) land on the same XCD's L2
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n0 = (bid % ntn) * BN;
+    int t = bid / ntn;
+    const int w0 = (t % ntw) * TW; t /= ntw;
+    const int h0 = (t % nth) * TH8; t /= nth;
+    const int f0 = (t % ntf) * TF;
+    const int b = t / ntf;
+    const int K = p.C0 + p.C1;
+
+    // halo bookkeeping kept small (the accumulators own most of the register file): a validity bit mask, and the point
+    // index relative to the sample as a 32-bit offset (the LDS slot is recomputed where it is needed)
+    unsigned hokm = 0;
+    const float* xb0 = p.a0 + (long long)b * p.F * p.H * p.W * p.C0;
+    const float* xb1 = p.a1 ? p.a1 + (long long)b * p.F * p.H * p.W * p.C1 : nullptr;
+#pragma unroll
+    for (int i = 0; i < HLOADS; ++i) {
+        const int pt = (tid + 256 * i) >> 2;
+        const int pf = pt / (HH8 * HWL), ph = (pt / HWL) % HH8, pw = pt % HWL;
+        const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
+        if (pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) hokm |= 1u << i;
+    }
+    auto hpt_of = [&](int i) {
+        const int pt = (tid + 256 * i) >> 2;
+        const int pf = pt / (HH8 * HWL), ph = (pt / HWL) % HH8, pw = pt % HWL;
+        return ((f0 - 1 + pf) * p.H + (h0 - 1 + ph)) * p.W + (w0 - 1 + pw);
+    };
+    const int hslot = (tid & 3) * 4;
+    auto hdst_of = [&](int i) {
+        const int q = tid + 256 * i, pt = q >> 2;
+        return ((pt / HWL) * HWD + pt % HWL) * PST + (q & 3) * 8;          // + plane*32
+    };
+
+    f32x4 hreg[HLOADS];
+    uint4 hpk[HLOADS];
+    auto load_halo = [&](int kc) {
+        const int c = kc * KC + hslot;
+        const float* src;
+        int cs, cc;
+        if (c < p.C0) { src = xb0; cs = p.C0; cc = c; }
+        else { src = xb1; cs = p.C1; cc = c - p.C0; }
+        const bool cok = c < K;
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && ((hokm >> i) & 1)) v = *reinterpret_cast<const f32x4*>(src + (long long)hpt_of(i) * cs + cc);
+            hreg[i] = v;
+        }
+    };
+    // producer's GroupNorm -> (scale + 1, shift) -> SiLU (Block.forward, ...conv3d.py:196-204) when fused, then pre-scale and
+    // split; the zero padding of the convolution applies to the ACTIVATED tensor, so out-of-range points stay 0
+    auto prepare_halo = [&](int kc) {
+        if (p.in_coef) {
+            const int c = kc * KC + hslot;
+            if (c < K) {
+                const f32x4* cf = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b * (K >> 2) + (c >> 2)) * 5;
+                const f32x4 mu = cf[0], ga = cf[1], be = cf[2], sc = cf[3], sh = cf[4];
+#pragma unroll
+                for (int i = 0; i < HLOADS; ++i) {
+                    if ((hokm >> i) & 1) {
+                        f32x4 y = (hreg[i] - mu) * ga + be;
+                        y = y * sc + sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
+                        hreg[i] = y;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            uint2 p1, p2;
+            split2(hreg[i] * SA, p1, p2);
+            hpk[i] = uint4{p1.x, p1.y, p2.x, p2.y};
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HLOADS; ++i) {
+            if (tid + 256 * i < NLOG * 4) {
+                const int d = hdst_of(i);
+                *reinterpret_cast<uint2*>(halo + d) = uint2{hpk[i].x, hpk[i].y};
+                *reinterpret_cast<uint2*>(halo + d + 32) = uint2{hpk[i].z, hpk[i].w};
+            }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    const int a_lane = (((wm * 2) * HH8 + lh) * HWD + lw) * PST + hh * 16;
+    const unsigned char* wlane = reinterpret_cast<const unsigned char*>(p.wp) +
+                                 ((long long)n0 + wn * (BN / WN) + l31) * WROW + hh * 16;
+    f16x8 w[3][NT][2];
+    f16x8 a[2][MT][2];
+    // the weight stream is walked with ONE running pointer (order: taps 0..26 of chunk 0, taps 0..26 of chunk 1, ...): with the
+    // taps unrolled, per-tap base addresses would otherwise be hoisted into ~54 registers
+    const long long wstride = (long long)p.Npad * WROW, wtap = wstride * p.kchunks;
+    const unsigned char* wnext = wlane;
+    int wtap_i = 0, wkc_i = 0;
+    auto ldw = [&](int, int, f16x8 (&dst)[NT][2]) {
+        const unsigned char* src = wnext;
+        if (++wtap_i == 27) { wtap_i = 0; ++wkc_i; wnext = wlane + wkc_i * wstride; }
+        else wnext += wtap;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) dst[nt][pl] = *reinterpret_cast<const f16x8*>(src + nt * 32 * WROW + pl * 32);
+    };
+    auto lda = [&](int tap, f16x8 (&dst)[MT][2]) {
+        const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int aoff = a_lane + ((df * HH8 + dh) * HWD + dw) * PST;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                dst[mt][pl] = *reinterpret_cast<const f16x8*>(halo + aoff + (((mt >> 1) * HH8 + 4 * (mt & 1)) * HWD) * PST + pl * 32);
+    };
+    load_halo(0);
+    ldw(0, 0, w[0]);
+    ldw(1, 0, w[1]);
+    prepare_halo(0);
+    store_halo();
+    __syncthreads();
+    lda(0, a[0]);
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+        const bool more_kc = kc + 1 < p.kchunks;
+        auto tap_body = [&](int tap) {
+            const int tw = tap + 2;
+            if (tw < 27) ldw(tw, kc, w[tw % 3]);
+            else if (more_kc) ldw(tw - 27, kc + 1, w[tw % 3]);
+            if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+            // pin the prefetches HERE: without the scheduling barrier the compiler hoists this tap's MFMAs above them (they are
+            // not memory operations), which leaves every load right in front of its first use -- no prefetch distance at all
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};     // small terms first
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap & 1][mt][PA[term]], w[tap % 3][nt][PB[term]],
+                                                                             acc[mt][nt], 0, 0, 0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // (the halo code stays OUTSIDE the unrolled tap loops: inside, the unroller gives up and the rings go to scratch)
+        // the next chunk's halo loads go BEHIND the tap-0 weight prefetch: vmcnt retires in order, so every weight load issued
+        // after them also waits for them -- this way the first such load is needed three taps (2300 cycles) later
+        tap_body(0);
+        if (more_kc) load_halo(kc + 1);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tap = 1; tap < 12; ++tap) tap_body(tap);
+        if (more_kc) prepare_halo(kc + 1);
+#pragma unroll
+        for (int tap = 12; tap < 27; ++tap) tap_body(tap);
+        if (more_kc) {
+            __syncthreads();
+            store_halo();
+            __syncthreads();
+            lda(0, a[0]);
+        }
+    }
+
+    // ---- epilogue: the launcher guarantees full tiles (F % TF == 0, H % 8 == 0, W % 8 == 0), so a slab's 32 points are a
+    //      fixed per-lane offset pattern from one base pointer (no bounds checks, no 64-bit address arithmetic per store)
+    int poff[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int ih, iw;
+        lane_hw((r & 3) + 8 * (r >> 2) + 4 * hh, ih, iw);
+        poff[r] = (ih * p.W + iw) * p.N;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * (BN / WN) + nt * 32 + l31;
+        const bool nok = n < p.N;
+        const float bv = (nok && p.bias) ? p.bias[n] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+        if (nok) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int f = f0 + wm * 2 + (mt >> 1), h = h0 + 4 * (mt & 1);
+                float* base = p.out + ((((long long)b * p.F + f) * p.H + h) * p.W + w0) * p.N + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mt][nt][r] * DESCALE + bv;
+                    base[poff[r]] = v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+        }
+        if (p.gn_part) {
+            // GroupNorm statistics of the OUTPUT: this wave's 4 slabs x 32 points of column n (fixed summation order)
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (hh == 0 && nok) {
+                const long long tile = ((long long)(f0 / TF) * nth + h0 / TH8) * ntw + w0 / TW;
+                float* dst = p.gn_part + ((((long long)b * ((long long)ntf * nth * ntw) + tile) * WM + wm) * p.N + n) * 2;
+                dst[0] = ssum;
+                dst[1] = ssq;
+            }
+        }
+    }
+}
+
+// which tiling a launch uses: 0 = (2 x 2)-accumulator kernel on 4x4x8 tiles, 1 = 8x4x8 tiles (64-wide), 2 = big-tile kernel
+static int conv3f3_variant(int F, int H, int W, int N, int Npad) {
+    static const int big_ok = [] { const char* e = getenv("DPC_CONV3F3_BIG"); return e ? atoi(e) : 1; }();
+    static const int tall_ok = [] { const char* e = getenv("DPC_CONV3F3_TALL"); return e ? atoi(e) : 1; }();
+    const bool wide = Npad % 128 == 0 && N > 64;
+    if (big_ok && F % (wide ? 4 : 8) == 0 && H % 8 == 0 && W % 8 == 0) return 2;
+    if (!wide && tall_ok && F % 8 == 0) return 1;
+    return 0;
+}
+
+// number of GroupNorm partial-sum entries per sample and channel that the conv epilogue writes ([B][entries][N][2])
+long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad) {
+    using namespace f3;
+    const bool wide = Npad % 128 == 0 && N > 64;
+    const int v = conv3f3_variant(F, H, W, N, Npad);
+    if (v == 2) {
+        const int tf = wide ? 4 : 8;
+        return (long long)(F / tf) * (H / 8) * (W / 8) * (wide ? 2 : 4);
+    }
+    const int tf = v == 1 ? 8 : 4;
+    return (long long)((F + tf - 1) / tf) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * (tf / 2);
+}
+
 int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     using namespace f3;
     DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv3f3: channel counts must be multiples of 4");
@@ -277,12 +553,29 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
-    static const int tall_ok = [] { const char* e = getenv("DPC_CONV3F3_TALL"); return e ? atoi(e) : 1; }();
     Conv3hParams pd = p;
     pd.dbg = dbg;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
+    const int variant = conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
+    if (variant == 2) {
+        const int tf = wide ? 4 : 8;
+        const long long tiles = (long long)p.B * (p.F / tf) * (p.H / 8) * (p.W / 8);
+        const long long grid = tiles * (p.Npad / (wide ? 128 : 64));
+        DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
+        const size_t lds = (size_t)(tf + 2) * f3b::HH8 * HWD * PST;
+        static bool once = false;
+        if (!once) {
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 10 * 12 * PST));
+            once = true;
+        }
+        if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        else hipLaunchKernelGGL((conv3f3b_kernel<64>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        DPC_LAUNCH_CHECK();
+        return DPC_OK;
+    }
     // the 8-frame tile keeps the GroupNorm partial-sum count of the 4-frame tiling (tiles x 2 == tiles8 x 4) iff F % 8 == 0
-    const bool tall = !wide && tall_ok && p.F % 8 == 0;
+    const bool tall = variant == 1;
     const int tf = tall ? 8 : 4;
     const long long tiles = (long long)p.B * ((p.F + tf - 1) / tf) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const size_t lds = (size_t)(tf + 2) * HH * HWD * PST;

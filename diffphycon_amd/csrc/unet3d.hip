@@ -263,7 +263,9 @@ struct Runner {
             // GroupNorm fused around the two conv3x6 launches: statistics come out of the conv epilogues, block1's
             // normalise + scale/shift + SiLU is applied inside block2's halo load (h1 never exists in HBM in activated
             // form), only block2's normalise + SiLU (+ residual) is a separate streaming pass.
-            const long long tiles = conv3x6_tiles_per_sample(F, Hl, Wl);
+            // GroupNorm partial sums per (sample, channel): 2 per 4x4x8 tile, or what the f16x3 tiling of this shape emits
+            const long long tiles = conv_mode_default() == 2 ? conv3f3_gn_entries(F, Hl, Wl, Cout, igemm_npad(Cout)) / 2
+                                                             : conv3x6_tiles_per_sample(F, Hl, Wl);
             const long long R = (long long)F * Hl * Wl;
             float* raw1 = ar.allocf(P * Cout);
             float* part = ar.allocf((long long)mb * tiles * 2 * Cout * 2);
