@@ -358,8 +358,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors in HBM and fp32 accumulation everywhere. 3x3x3 convs and the implicit-GEMM ops split each "
                           "operand into 2 fp16 terms (22 significant bits) and sum 3 partial products per product (f16x3); the "
-                          "stem, and the q/k/v/out projections and contractions of the fused temporal attention, use the exact "
-                          "3-way bf16 split with 6 partial products (bf16x6); fused linear attention uses the native fp32 MFMA. "
+                          "fused attention blocks at C = 64 use the same f16x3 scheme in registers; the stem and the C = 128 temporal "
+                          "attention use the exact 3-way bf16 split with 6 partial products (bf16x6), the C = 128 linear attention "
+                          "the native fp32 MFMA. "
                           "Measured U-Net forward deviation from the reference's fp32 CPU output: 2.3e-6 (f16x3) vs 3.1e-6 "
                           "(bf16x6) vs 2.7e-6 (native fp32 MFMA) of the output range (tools/mode_error.py); tolerance 1e-4. "
                           "DPC_CONV_MODE / DPC_IGEMM_MODE = x6 | f32 select the other kernels",
