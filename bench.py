@@ -37,8 +37,8 @@ def mfma_roof(name):
         mode = os.environ.get("DPC_CONV_MODE", "f16x3").lower()
     elif name.startswith("igemm"):
         mode = os.environ.get("DPC_IGEMM_MODE", "f16x3").lower()
-    elif name.startswith("stem") and os.environ.get("DPC_STEM_MODE", "x6")[:1].lower() != "f":
-        mode = "x6"
+    elif name.startswith("stem"):
+        mode = os.environ.get("DPC_STEM_MODE", "f16x3").lower()
     else:
         mode = "f32"
     if mode.startswith("f3"):
@@ -358,8 +358,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors in HBM and fp32 accumulation everywhere. 3x3x3 convs and the implicit-GEMM ops split each "
                           "operand into 2 fp16 terms (22 significant bits) and sum 3 partial products per product (f16x3); the "
-                          "fused attention blocks at C = 64 use the same f16x3 scheme in registers; the stem and the C = 128 temporal "
-                          "attention use the exact 3-way bf16 split with 6 partial products (bf16x6), the C = 128 linear attention "
+                          "stem and the fused attention blocks at C = 64 use the same f16x3 scheme; the C = 128 temporal "
+                          "attention uses the exact 3-way bf16 split with 6 partial products (bf16x6), the C = 128 linear attention "
                           "the native fp32 MFMA. "
                           "Measured U-Net forward deviation from the reference's fp32 CPU output: 2.3e-6 (f16x3) vs 3.1e-6 "
                           "(bf16x6) vs 2.7e-6 (native fp32 MFMA) of the output range (tools/mode_error.py); tolerance 1e-4. "

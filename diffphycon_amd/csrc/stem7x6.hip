@@ -9,6 +9,11 @@
 // are useful for C = 6).  Rows are 16 slots = 256 B; rows whose (h >> 1) is odd are rotated by 8 slots, so the two rows a
 // ds_read_b128 pass touches (h and h+2, see lane_hw in conv3x6.hip) always hit complementary bank halves: conflict-free.
 // Weights are pre-split [49][4][n][3 planes][16] bf16 and read as fragments straight from L2/L1, one k-step ahead.
+//
+// stem7x6_kernel<true> (default, DPC_STEM_MODE=f16x3) is the same kernel with the 2-way fp16 operand split of conv3f3.hip
+// (2 planes, 3 MFMAs per product, input pre-scaled by 2^4, weights by 2^12, epilogue rescale 2^-16).
+#include <type_traits>
+
 #include "common.h"
 
 namespace dpc {
@@ -44,13 +49,32 @@ __device__ __forceinline__ void split3_2(float a, float b, unsigned& p1, unsigne
     const float s0 = r0 - lo_f32(p2), s1 = r1 - hi_f32(p2);
     p3 = cvt_pk_bf16(s0, s1);
 }
+typedef _Float16 f16x2_s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+__device__ __forceinline__ void split2_2(float a, float b, unsigned& p1, unsigned& p2) {
+    a = sat16(a); b = sat16(b);
+    p1 = cvt_pk_f16(a, b);
+    const f16x2_s h = __builtin_bit_cast(f16x2_s, p1);
+    p2 = cvt_pk_f16(a - (float)h.x, b - (float)h.y);
+}
+constexpr float SA = 16.f, SW = 4096.f, DESCALE = 1.f / 65536.f;
 }  // namespace s7
 
 typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_s __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+template <bool H3>
 __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const unsigned char* __restrict__ wp6) {
     using namespace s7;
+    constexpr int NP = H3 ? 2 : 3;                                // operand planes
+    constexpr int WROWB = NP * 32;                                // packed weight bytes per (step, n)
+    using frag_t = std::conditional_t<H3, f16x8_s, bf16x8_s>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
     unsigned char* halo = smem7;                                  // [3 planes][HF][HH][16 slots][8 ch] bf16
 
@@ -88,15 +112,16 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
         u32x4 q1, q2, q3;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            unsigned a1, a2, a3;
-            split3_2(v[2 * c], v[2 * c + 1], a1, a2, a3);
+            unsigned a1, a2, a3 = 0;
+            if constexpr (H3) split2_2(v[2 * c] * SA, v[2 * c + 1] * SA, a1, a2);
+            else split3_2(v[2 * c], v[2 * c + 1], a1, a2, a3);
             q1[c] = a1; q2[c] = a2; q3[c] = a3;
         }
         const int rslot = (slot + (((ph >> 1) & 1) << 3)) & 15;   // bank rotation of rows with odd (h >> 1)
         unsigned char* dst = halo + row * ROWB + rslot * 16;
         *reinterpret_cast<u32x4*>(dst) = q1;
         *reinterpret_cast<u32x4*>(dst + PLANEB) = q2;
-        *reinterpret_cast<u32x4*>(dst + 2 * PLANEB) = q3;
+        if constexpr (!H3) *reinterpret_cast<u32x4*>(dst + 2 * PLANEB) = q3;
     }
 
     f32x16 acc[2];
@@ -108,13 +133,13 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
     int lh, lw;
     lane_hw(l31, lh, lw);
     // weight fragments: [(df*7+dh)*4 + ks][Npad][3][16] bf16 = 96 B per n
-    const unsigned char* wlane = wp6 + ((long long)n0 + wn * 32 + l31) * 96 + hh * 16;
-    const long long wstep = (long long)p.Npad * 96;
-    bf16x8_s wc[3], wx[3];
-    auto ldw = [&](int step, bf16x8_s (&w)[3]) {
+    const unsigned char* wlane = wp6 + ((long long)n0 + wn * 32 + l31) * WROWB + hh * 16;
+    const long long wstep = (long long)p.Npad * WROWB;
+    frag_t wc[NP], wx[NP];
+    auto ldw = [&](int step, frag_t (&w)[NP]) {
         const unsigned char* src = wlane + (long long)step * wstep;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w[pl] = *reinterpret_cast<const bf16x8_s*>(src + pl * 32);
+        for (int pl = 0; pl < NP; ++pl) w[pl] = *reinterpret_cast<const frag_t*>(src + pl * 32);
     };
     ldw(0, wc);
     __syncthreads();
@@ -129,20 +154,29 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
                 const int step = (df * 7 + dh) * 4 + ks;
                 if (step + 1 < 196) ldw(step + 1, wx);
                 const int slot = (lw + 2 * ks + hh + rot) & 15;
-                bf16x8_s a[2][3];
+                frag_t a[2][NP];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        a[mt][pl] = *reinterpret_cast<const bf16x8_s*>(halo + pl * PLANEB + row0 + mt * (HH * ROWB) + slot * 16);
-                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
+                    for (int pl = 0; pl < NP; ++pl)
+                        a[mt][pl] = *reinterpret_cast<const frag_t*>(halo + pl * PLANEB + row0 + mt * (HH * ROWB) + slot * 16);
+                if constexpr (H3) {
+                    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};                       // small terms first
 #pragma unroll
-                for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < 3; ++term)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
+                } else {
+                    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};     // smallest terms first
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wc[pl] = wx[pl];
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) wc[pl] = wx[pl];
             }
         }
     }
@@ -161,14 +195,19 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
                 lane_hw(i, ih, iw);
                 const int h = h0 + ih, w = w0 + iw;
                 if (h < p.H && w < p.W)
-                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][r] + bv;
+                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][r] * (H3 ? DESCALE : 1.f) + bv;
             }
         }
     }
 }
 
 bool stem7x6_supported(int C, int k) { return k == 7 && C >= 1 && C <= 8; }
-size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }
+size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }      // sized for 3 planes; f16x3 uses 64 of the 96 B
+
+static bool stem_h3() {
+    static const bool v = [] { const char* e = getenv("DPC_STEM_MODE"); return !(e && (e[0] == 'x' || e[0] == 'b')); }();
+    return v;
+}
 
 int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     using namespace s7;
@@ -179,17 +218,23 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     const long long tiles = (long long)B * ((p.F + TF - 1) / TF) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const long long grid = tiles * (p.Npad / 64);
     DPC_REQUIRE(grid < (1ll << 31), "stem7x6: grid too large");
-    const size_t lds = 3 * (size_t)PLANEB;
+    const bool h3 = stem_h3();
+    const size_t lds = (h3 ? 2 : 3) * (size_t)PLANEB;
     ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * 343.0 * p.C, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
     static bool once = false;
-    if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
-    hipLaunchKernelGGL(stem7x6_kernel, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
+    if (!once) {
+        DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PLANEB));
+        DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PLANEB));
+        once = true;
+    }
+    if (h3) hipLaunchKernelGGL(stem7x6_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
+    else hipLaunchKernelGGL(stem7x6_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
 
 // reference weight [N][C][7][7][7] fp32 -> [(df*7+dh)*4 + ks][Npad][3 planes][16] bf16, k = (dw - 2 ks) * 8 + c
-__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C) {
+__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C, int h3) {
     const long long total = 196ll * Npad * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 16);
@@ -200,6 +245,15 @@ __global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short*
         const int dw = 2 * ks + (kk >> 3), c = kk & 7;
         float v = 0.f;
         if (n < N && c < C && dw < 7) v = w[(((long long)n * C + c) * 7 + df) * 49 + dh * 7 + dw];
+        if (h3) {
+            v = s7::sat16(v * s7::SW);
+            const unsigned h1 = s7::cvt_pk_f16(v, 0.f) & 0xffffu;
+            const unsigned h2 = s7::cvt_pk_f16(v - (float)__builtin_bit_cast(s7::f16x2_s, h1).x, 0.f) & 0xffffu;
+            unsigned short* d3 = wp + ((long long)step * Npad + n) * 32 + kk;
+            d3[0] = (unsigned short)h1;
+            d3[16] = (unsigned short)h2;
+            continue;
+        }
         const unsigned p1 = s7::cvt_pk_bf16(v, 0.f) & 0xffffu;
         const float r1 = v - __uint_as_float(p1 << 16);
         const unsigned p2 = s7::cvt_pk_bf16(r1, 0.f) & 0xffffu;
@@ -215,7 +269,8 @@ __global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short*
 int launch_pack_stem7x6(const float* w, void* wp6, int N, int Npad, int C, hipStream_t s) {
     const long long total = 196ll * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_stem7x6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad, C);
+    hipLaunchKernelGGL(pack_stem7x6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad, C,
+                       stem_h3() ? 1 : 0);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -567,7 +567,7 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
         if ((rc = h->stem_wp->alloc((size_t)h->stem_kchunks * h->stem_npad * 32 * sizeof(float)))) return rc;
         if ((rc = h->stem_ktab->alloc((size_t)h->stem_kchunks * 32 * sizeof(int)))) return rc;
         rc = launch_pack_stem(w, h->stem_wp->f(), (int*)h->stem_ktab->p, N, h->stem_npad, C, k, s);
-        static const bool stem_f32 = [] { const char* e = getenv("DPC_STEM_MODE"); return e && (e[0] == 'f' || e[0] == 'F'); }();
+        static const bool stem_f32 = [] { const char* e = getenv("DPC_STEM_MODE"); return e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3'; }();
         h->stem_wp6.reset();
         if (!rc && !stem_f32 && stem7x6_supported(C, k)) {
             h->stem_wp6.reset(new DevBuf());
