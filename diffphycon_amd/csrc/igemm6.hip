@@ -391,32 +391,40 @@ __global__ __launch_bounds__(256, 2) void igemm3_kernel(IgemmParams p, const uns
         }
         __syncthreads();
     }
-    // ---- epilogue (same accumulator layout and output modes as igemm.hip)
+    // ---- epilogue (accumulator layout and output modes of igemm.hip).  Row-major loop: the output row offset -- two integer
+    //      divisions in the channel-first and ConvTranspose-parity modes -- is computed once per accumulator row, not per element
+    float bv[NT];
+    int ncol[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        ncol[nt] = n0 + wn * (BN / 2) + nt * 32 + l31;
+        bv[nt] = (ncol[nt] < p.N && p.bias) ? p.bias[ncol[nt]] : 0.f;
+    }
+    const long long cstride = p.out_mode == 1 ? (long long)HoWo : 1ll;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (m >= p.M) continue;
-                float v = acc[mt][nt][r] * DESCALE + bv;
-                if (p.resid) v += p.resid[m * p.N + n];
-                long long o;
-                if (p.out_mode == 0) {
-                    o = m * p.N + n;
-                } else if (p.out_mode == 1) {
-                    const long long bf = m / HoWo, hw = m - bf * HoWo;
-                    o = (bf * p.N + n) * (long long)HoWo + hw;
-                } else {
-                    const long long bf = m / HoWo;
-                    const int hw = (int)(m - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
-                    o = ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N + n;
-                }
-                p.out[o] = v;
+        for (int r = 0; r < 16; ++r) {
+            const long long m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m >= p.M) continue;
+            long long orow;
+            if (p.out_mode == 0) {
+                orow = m * p.N;
+            } else if (p.out_mode == 1) {
+                const long long bf = m / HoWo, hw = m - bf * HoWo;
+                orow = bf * p.N * (long long)HoWo + hw;
+            } else {
+                const long long bf = m / HoWo;
+                const int hw = (int)(m - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
+                orow = ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N;
+            }
+            const float* rrow = p.resid ? p.resid + m * p.N : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (ncol[nt] >= p.N) continue;
+                float v = acc[mt][nt][r] * DESCALE + bv[nt];
+                if (rrow) v += rrow[ncol[nt]];
+                p.out[orow + ncol[nt] * cstride] = v;
             }
         }
     }
