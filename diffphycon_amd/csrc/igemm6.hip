@@ -245,8 +245,12 @@ __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
 
 typedef _Float16 f16x8_g __attribute__((ext_vector_type(8)));
 
+// Occupancy matters more than anything else for this family (streaming ops, MFMA 7 % busy): the 64-wide kernel is held to
+// 128 VGPRs so that four workgroups share a CU (4 x 37 KB LDS).  A deeper A-prefetch ring was measured slower: it costs
+// registers (fewer workgroups), and vmcnt retires in order, so the per-iteration wait for the next weight fragments also waits
+// for every younger A prefetch.
 template <int BN>
-__global__ __launch_bounds__(256, 2) void igemm3_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+__global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace g3;
     constexpr int NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
