@@ -272,21 +272,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
     // ---- per-thread A rows: 4 rows (tid/8 + 32 i), one float4 column (tid%8)*4   (identical to igemm.hip)
     const int arow = tid >> 3, acol = (tid & 7) * 4;
     const int HoWo = p.Ho * p.Wo;
-    int r_bf[4], r_f[4], r_h[4], r_w[4];
-    bool r_ok[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long long m = m0 + arow + 32 * i;
-        r_ok[i] = m < p.M;
-        const long long mm = r_ok[i] ? m : 0;
-        const int bf = (int)(mm / HoWo);
-        const int hw = (int)(mm - (long long)bf * HoWo);
-        const int ho = hw / p.Wo;
-        r_bf[i] = bf;
-        r_f[i] = bf % p.F;
-        r_h[i] = ho * p.sh;
-        r_w[i] = (hw - ho * p.Wo) * p.sw;
-    }
+    // (the row -> (frame, y, x) decomposition is redone at every tap change instead of being kept in 16 registers: the
+    //  64-wide kernel must fit 128 VGPRs WITHOUT spilling -- a spilling build gave micro-batch-dependent results)
     const int K = p.C0 + p.C1;
     f32x4 ra[4];
     long long roff[4];
@@ -299,10 +286,15 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
             const int df = p.tdf[tap], dh = p.tdh[tap], dw = p.tdw[tap];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int fi = r_f[i] + df, hi = r_h[i] + dh, wi = r_w[i] + dw;
-                rvalid[i] = r_ok[i] && (unsigned)fi < (unsigned)p.F && (unsigned)hi < (unsigned)p.Hi &&
-                            (unsigned)wi < (unsigned)p.Wi;
-                roff[i] = ((long long)(r_bf[i] + df) * p.Hi + hi) * p.Wi + wi;
+                const long long m = m0 + arow + 32 * i;
+                const bool ok = m < p.M;
+                const long long mm = ok ? m : 0;
+                const int bf = (int)(mm / HoWo);
+                const int hw = (int)(mm - (long long)bf * HoWo);
+                const int ho = hw / p.Wo;
+                const int fi = bf % p.F + df, hi = ho * p.sh + dh, wi = (hw - ho * p.Wo) * p.sw + dw;
+                rvalid[i] = ok && (unsigned)fi < (unsigned)p.F && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+                roff[i] = ((long long)(bf + df) * p.Hi + hi) * p.Wi + wi;
             }
         }
         const int c = kc * BK + acol;

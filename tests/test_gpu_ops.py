@@ -48,6 +48,12 @@ CONV_CASES = [
     (2, 4, 16, 16, 64, 64, (1, 4, 4), (1, 2, 2), (0, 1, 1)),
     (2, 3, 8, 8, 128, 6, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (1, 2, 6, 10, 40, 72, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # shapes the big-tile f16x3 kernel takes (F % 8 == 0 / F % 4 == 0 for Cout > 64, H % 8 == 0, W % 8 == 0)
+    (1, 8, 16, 16, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 8, 8, 16, 128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 4, 16, 8, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 8, 8, 8, 48, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 16, 8, 8, 20, 40, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 ]
 
 
