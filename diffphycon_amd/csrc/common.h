@@ -164,10 +164,11 @@ int launch_pack_attn6(const float* w, unsigned char* dst, int C, bool is_out, hi
 int launch_tattn6(const TattnParams& p, const unsigned char* wq6, const unsigned char* wo6, int C, hipStream_t s);
 // persistent weight-stationary f16x3 version for C = 64 (tattn3.hip)
 bool tattn3_supported(int C, int F, int heads);
-size_t tattn3_qkv_bytes();
-size_t tattn3_out_bytes();
-int launch_pack_tattn3(const float* w, unsigned char* dst, bool is_out, hipStream_t s);
-int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, hipStream_t s);
+size_t tattn3_qkv_bytes(int C);
+size_t tattn3_out_bytes(int C);
+size_t tattn3_workspace_bytes(int C, long long rows);      // C = 128: partial to_out sums of the first head pair
+int launch_pack_tattn3(const float* w, unsigned char* dst, int C, bool is_out, hipStream_t s);
+int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, void* workspace, hipStream_t s);
 // single-launch weight-stationary f16x3 linear attention for C = 64 (lattn3.hip); same weight images as tattn3; p.ctx unused
 bool lattn3_supported(int C, int heads);
 int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned char* wo3, hipStream_t s);

@@ -17,25 +17,34 @@ namespace dpc {
 
 using namespace h3;
 
+// C = 64: all four heads resident, one launch.  C = 128: the weights of two heads (128 KB) fit, so the block runs as two
+// launches over head pairs: pass 1 (heads 0, 1) writes its partial to_out sum to a workspace, pass 2 (heads 2, 3) adds it,
+// the residual and its own sum.
+template <int C_>
+struct T3 {
+    static constexpr int C = C_, KS = C / 16, NTC = C / 32;
+    static constexpr int NH = C == 64 ? 4 : 2;                // heads resident per launch
+    static constexpr int HEAD_QKV = 3 * KS * 2048;            // bytes per head: q | k | v, each KS x 2 planes x 1 KB
+    static constexpr int HEAD_OUT = NTC * 2 * 2048;           // bytes per head: NTC column tiles x 2 k-steps x 2 planes x 1 KB
+    static constexpr int QKV_RES = NH * HEAD_QKV, OUT_RES = NH * HEAD_OUT;
+    static constexpr int TS = 36;                             // padded row stride (floats) of the rotary / bias tables in LDS
+    static constexpr int OFF_COS = QKV_RES + OUT_RES, OFF_SIN = OFF_COS + 32 * TS * 4, OFF_BIAS = OFF_SIN + 32 * TS * 4;
+    static constexpr int LDS_BYTES = OFF_BIAS + NH * 32 * TS * 4;          // 158720 (C = 64), 149504 (C = 128)
+};
 namespace t3 {
-constexpr int C = 64, KS = C / 16, NTC = C / 32;
-constexpr int HEAD_QKV = 3 * KS * 2048;            // bytes per head: q | k | v, each KS x 2 planes x 1 KB
-constexpr int HEAD_OUT = NTC * 2 * 2048;           // bytes per head: NTC column tiles x 2 k-steps x 2 planes x 1 KB
-constexpr int QKV_ALL = 4 * HEAD_QKV, OUT_ALL = 4 * HEAD_OUT;
-constexpr int TS = 36;                             // padded row stride (floats) of the rotary / bias tables in LDS
-constexpr int OFF_COS = QKV_ALL + OUT_ALL, OFF_SIN = OFF_COS + 32 * TS * 4, OFF_BIAS = OFF_SIN + 32 * TS * 4;
-constexpr int LDS_BYTES = OFF_BIAS + 4 * 32 * TS * 4;          // 158720
+constexpr int TS = 36;
 constexpr float SX = 16.f, SWGT = 4096.f;
 constexpr float PROJ_DESCALE = 1.f / (SX * SWGT);  // accumulator -> true value of a projection
 constexpr float SQK = 16.f, SP = 1024.f, SV = 16.f, SO = 16.f;
 }  // namespace t3
 
-size_t tattn3_qkv_bytes() { return t3::QKV_ALL; }
-size_t tattn3_out_bytes() { return t3::OUT_ALL; }
+size_t tattn3_qkv_bytes(int C) { return (size_t)4 * 3 * (C / 16) * 2048; }
+size_t tattn3_out_bytes(int C) { return (size_t)4 * (C / 32) * 2 * 2048; }
 
-// to_qkv.weight [384][64] -> [head][q|k|v][ks][plane][32 rows][2][8];  to_out.weight [64][128] -> [head][nt][s][plane][32][2][8]
-__global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int is_out, int total) {
+// to_qkv.weight [384][C] -> [head][q|k|v][ks][plane][32 rows][2][8];  to_out.weight [C][128] -> [head][nt][s][plane][32][2][8]
+__global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int C, int is_out, int total) {
     using namespace t3;
+    const int KS = C / 16, NTC = C / 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one value = 2 planes
     if (idx >= total) return;
     const int i = idx & 7, hh = (idx >> 3) & 1, r = (idx >> 4) & 31;
@@ -61,30 +70,37 @@ __global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* 
     dst[o + 512] = (unsigned short)p2;
 }
 
-int launch_pack_tattn3(const float* w, unsigned char* dst, bool is_out, hipStream_t s) {
-    using namespace t3;
-    const int total = is_out ? 4 * NTC * 2 * 512 : 4 * 3 * KS * 512;
+int launch_pack_tattn3(const float* w, unsigned char* dst, int C, bool is_out, hipStream_t s) {
+    const int total = is_out ? 4 * (C / 32) * 2 * 512 : 4 * 3 * (C / 16) * 512;
     hipLaunchKernelGGL(pack_tattn3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(dst),
-                       is_out ? 1 : 0, total);
+                       C, is_out ? 1 : 0, total);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
 
 __device__ __forceinline__ int rowmap3(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-template <bool FULL>     // FULL: F == 32, no token masks
+// FULL: F == 32, no token masks.  PASS: 0 = all heads in one launch (C = 64); 1 / 2 = first / second head pair (C = 128),
+// `part` = [rows][C] partial to_out sums written by pass 1 and consumed by pass 2.
+template <int C_, bool FULL, int PASS>
 __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const unsigned char* __restrict__ wq3,
-                                                        const unsigned char* __restrict__ wo3) {
+                                                        const unsigned char* __restrict__ wo3, float* __restrict__ part) {
     using namespace t3;
+    using G = T3<C_>;
+    constexpr int C = G::C, KS = G::KS, NTC = G::NTC, NH = G::NH, HEAD_QKV = G::HEAD_QKV, HEAD_OUT = G::HEAD_OUT;
+    constexpr int QKV_RES = G::QKV_RES, OUT_RES = G::OUT_RES, OFF_COS = G::OFF_COS, OFF_SIN = G::OFF_SIN, OFF_BIAS = G::OFF_BIAS;
+    constexpr int HD0 = PASS == 2 ? 2 : 0;             // first resident head
+    constexpr bool PREFETCH = C == 64;                 // C = 128: the row registers are needed for xs / y
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int loff = l31 * 32 + hh * 16;
     const int F = p.F;
 
     // ---- one-time fill: weight images verbatim, rotary / bias tables with padded rows
-    for (int q = tid; q < QKV_ALL / 16; q += 512) reinterpret_cast<uint4*>(smem3)[q] = reinterpret_cast<const uint4*>(wq3)[q];
-    for (int q = tid; q < OUT_ALL / 16; q += 512)
-        reinterpret_cast<uint4*>(smem3 + QKV_ALL)[q] = reinterpret_cast<const uint4*>(wo3)[q];
+    for (int q = tid; q < QKV_RES / 16; q += 512)
+        reinterpret_cast<uint4*>(smem3)[q] = reinterpret_cast<const uint4*>(wq3 + (size_t)HD0 * HEAD_QKV)[q];
+    for (int q = tid; q < OUT_RES / 16; q += 512)
+        reinterpret_cast<uint4*>(smem3 + QKV_RES)[q] = reinterpret_cast<const uint4*>(wo3 + (size_t)HD0 * HEAD_OUT)[q];
     {
         float* cosL = reinterpret_cast<float*>(smem3 + OFF_COS);
         float* sinL = reinterpret_cast<float*>(smem3 + OFF_SIN);
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             cosL[r * TS + c] = r < F ? p.rot_cos[r * 32 + c] : 1.f;
             sinL[r * TS + c] = r < F ? p.rot_sin[r * 32 + c] : 0.f;
         }
-        for (int q = tid; q < 4 * 32 * 32; q += 512) biasL[(q >> 5) * TS + (q & 31)] = p.bias32[q];
+        for (int q = tid; q < NH * 32 * 32; q += 512) biasL[(q >> 5) * TS + (q & 31)] = p.bias32[HD0 * 1024 + q];
     }
     __syncthreads();
 
@@ -121,10 +137,11 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
 #pragma unroll
             for (int q = 0; q < 2; ++q) xr[ks][q] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4 * q);
     };
-    if (gp < p.npix) load_rows(row0_of(gp));
+    if (PREFETCH && gp < p.npix) load_rows(row0_of(gp));
 
     for (; gp < p.npix; gp += nwaves) {
         const long long row0 = row0_of(gp);
+        if (!PREFETCH) load_rows(row0);
         // ---- LayerNorm over channels (lane pair), scale, split
         f16x8 xs[KS][2];
         {
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             }
         }
         // ---- prefetch the next pixel's rows (consumed at the top of the next iteration)
-        if (gp + nwaves < p.npix) load_rows(row0_of(gp + nwaves));
+        if (PREFETCH && gp + nwaves < p.npix) load_rows(row0_of(gp + nwaves));
         asm volatile("" ::: "memory");
 
         f32x16 y[NTC];
@@ -172,9 +189,9 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             for (int r = 0; r < 16; ++r) y[nt][r] = 0.f;
 
 #pragma unroll 1
-        for (int hd = 0; hd < 4; ++hd) {
+        for (int hd = 0; hd < NH; ++hd) {
             const unsigned char* Wq = smem3 + hd * HEAD_QKV;
-            const unsigned char* Wo = smem3 + QKV_ALL + hd * HEAD_OUT;
+            const unsigned char* Wo = smem3 + QKV_RES + hd * HEAD_OUT;
             // ---- projections: Q^T, K^T (A = weights: lane = token, regs = head dims), V (A = x: lane = d, regs = token)
             f32x16 qT, kT, vv;
 #pragma unroll
@@ -274,28 +291,46 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             for (int r = 0; r < 16; ++r) {           // residual loads first, unconditional (clamped token), then the stores
                 const int i = rowmap3(r, hh);
                 const int ic = (FULL || i < F) ? i : 0;
-                res[r] = p.x[(row0 + (long long)ic * HW) * C + nt * 32 + l31];
+                const long long o = (row0 + (long long)ic * HW) * C + nt * 32 + l31;
+                res[r] = PASS == 1 ? 0.f : (PASS == 2 ? part[o] + p.x[o] : p.x[o]);
             }
+            float* dstp = PASS == 1 ? part : p.out;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = rowmap3(r, hh);
-                if (FULL || i < F) p.out[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+                if (FULL || i < F) dstp[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
             }
         }
     }
 }
 
-bool tattn3_supported(int C, int F, int heads) { return C == 64 && F <= 32 && heads == 4; }
+bool tattn3_supported(int C, int F, int heads) { return (C == 64 || C == 128) && F <= 32 && heads == 4; }
+size_t tattn3_workspace_bytes(int C, long long rows) { return C == 128 ? (size_t)rows * C * sizeof(float) : 0; }
 
-int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, hipStream_t s) {
-    using namespace t3;
+template <int C, int PASS>
+static void launch_t3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, float* part, long long grid,
+                      hipStream_t s) {
+    constexpr int LDS = T3<C>::LDS_BYTES;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)tattn3_kernel<C, true, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)tattn3_kernel<C, false, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once = true;
+    }
+    if (p.F == 32) hipLaunchKernelGGL((tattn3_kernel<C, true, PASS>), dim3((unsigned)grid), dim3(512), LDS, s, p, wq3, wo3, part);
+    else hipLaunchKernelGGL((tattn3_kernel<C, false, PASS>), dim3((unsigned)grid), dim3(512), LDS, s, p, wq3, wo3, part);
+}
+
+int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, void* workspace,
+                  hipStream_t s) {
     DPC_REQUIRE(tattn3_supported(C, p.F, 4), "tattn3: unsupported shape");
     DPC_REQUIRE(p.bias32, "tattn3: padded bias table missing");
+    DPC_REQUIRE(C == 64 || workspace, "tattn3: the C = 128 form needs its partial-sum workspace");
     if (p.npix == 0) return DPC_OK;
     DPC_REQUIRE(p.npix < (1ll << 31), "tattn3: too many sequences for one launch");
     const double rows = (double)p.npix * p.F;
     ProfScope prof(PROF_TATTN_FUSED, 2.0 * rows * C * 384 + 4.0 * rows * p.F * 32 * 4 + 2.0 * rows * 128 * C,
-                   4.0 * rows * C * 2, s);
+                   4.0 * rows * C * (C == 64 ? 2 : 5), s);
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;
@@ -303,12 +338,15 @@ int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned
         DPC_HIP(hipGetDevice(&dev));
         DPC_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount;
-        DPC_HIP(hipFuncSetAttribute((const void*)tattn3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        DPC_HIP(hipFuncSetAttribute((const void*)tattn3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     }
     const long long grid = std::min<long long>((p.npix + 7) / 8, ncu);
-    if (p.F == 32) hipLaunchKernelGGL(tattn3_kernel<true>, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, wq3, wo3);
-    else hipLaunchKernelGGL(tattn3_kernel<false>, dim3((unsigned)grid), dim3(512), LDS_BYTES, s, p, wq3, wo3);
+    if (C == 64) {
+        launch_t3<64, 0>(p, wq3, wo3, nullptr, grid, s);
+    } else {
+        launch_t3<128, 1>(p, wq3, wo3, reinterpret_cast<float*>(workspace), grid, s);
+        DPC_LAUNCH_CHECK();
+        launch_t3<128, 2>(p, wq3, wo3, reinterpret_cast<float*>(workspace), grid, s);
+    }
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

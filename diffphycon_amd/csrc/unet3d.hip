@@ -366,9 +366,14 @@ struct Runner {
             const float* o6 = raw_opt(p + ".fn.fn.fn.to_out.weight#x6");
             const float* q3 = raw_opt(p + ".fn.fn.fn.to_qkv.weight#h3");
             const float* o3 = raw_opt(p + ".fn.fn.fn.to_out.weight#h3");
-            if (h->attn_mode == 2 && q3 && o3 && tattn3_supported(C, F, h->cfg.attn_heads))
-                RUN(launch_tattn3(tp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), C, s));
-            else if (h->attn_mode >= 1 && q6 && o6)
+            if (h->attn_mode == 2 && tattn3_supported(C, F, h->cfg.attn_heads)) {
+                const size_t m3 = ar.mark();
+                void* ws3 = ar.alloc(tattn3_workspace_bytes(C, P));        // (allocated in the dry run as well)
+                if (q3 && o3)
+                    RUN(launch_tattn3(tp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), C,
+                                      ws3, s));
+                ar.release(m3);
+            } else if (h->attn_mode >= 1 && q6 && o6)
                 RUN(launch_tattn6(tp, reinterpret_cast<const unsigned char*>(q6), reinterpret_cast<const unsigned char*>(o6), C, s));
             else
                 RUN(launch_tattn_fused(tp, C, s));
@@ -607,10 +612,10 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
             rc = launch_pack_attn6(w, reinterpret_cast<unsigned char*>(b6->p), C, is_out, s);
             h->raw[name + "#x6"] = std::move(b6);
         }
-        if (!rc && inner == 128 && C == 64) {     // weight-stationary f16x3 attention kernels (tattn3.hip, lattn3.hip)
+        if (!rc && inner == 128 && (C == 64 || C == 128)) {     // weight-stationary f16x3 attention kernels (tattn3.hip, lattn3.hip)
             auto b3 = std::make_unique<DevBuf>();
-            if ((rc = b3->alloc(is_out ? tattn3_out_bytes() : tattn3_qkv_bytes()))) return rc;
-            rc = launch_pack_tattn3(w, reinterpret_cast<unsigned char*>(b3->p), is_out, s);
+            if ((rc = b3->alloc(is_out ? tattn3_out_bytes(C) : tattn3_qkv_bytes(C)))) return rc;
+            rc = launch_pack_tattn3(w, reinterpret_cast<unsigned char*>(b3->p), C, is_out, s);
             h->raw[name + "#h3"] = std::move(b3);
         }
     } else {
