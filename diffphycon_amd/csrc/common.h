@@ -171,7 +171,7 @@ int launch_pack_tattn3(const float* w, unsigned char* dst, int C, bool is_out, h
 int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, void* workspace, hipStream_t s);
 // single-launch weight-stationary f16x3 linear attention for C = 64 (lattn3.hip); same weight images as tattn3; p.ctx unused
 bool lattn3_supported(int C, int heads);
-int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned char* wo3, hipStream_t s);
+int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, hipStream_t s);
 
 // "gather" variant for the 7x7x7 stem on the reference-layout input [BF, C, H, W] (K = taps*C flattened)
 struct StemParams {

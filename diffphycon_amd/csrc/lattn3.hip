@@ -18,23 +18,37 @@ namespace dpc {
 
 using namespace h3;
 
+// C = 64: phase-1 weights (64 KB), phase-2 weights (64 KB), contexts and merge state are resident together.
+// C = 128: both weight sets are 128 KB, so they SHARE region A: Wk | Wv during phase 1, then (after the merge, which also uses
+// region A as scratch) the workgroup re-stages Wq | Wout into it for phase 2; contexts and merge state sit behind it.
+template <int C_>
+struct L3 {
+    static constexpr int C = C_, KS = C / 16, NTC = C / 32;
+    static constexpr int HEAD_QKV = 3 * KS * 2048;            // global image: [head][q|k|v][ks][plane][1 KB]   (pack_tattn3 layout)
+    static constexpr int HEAD_OUT = NTC * 2 * 2048;           // global image: [head][nt][s][plane][1 KB]
+    static constexpr int A_BYTES = 4 * 2 * KS * 2048;         // [head][k|v][ks][plane][1 KB]: 64 / 128 KB
+    static constexpr bool SHARED = C > 64;                    // phase-2 weights re-staged into region A
+    static constexpr int OFF_WQ = SHARED ? 0 : A_BYTES, OFF_WO = OFF_WQ + 4 * KS * 2048;
+    static constexpr int OFF_CTX = SHARED ? A_BYTES : OFF_WO + 4 * HEAD_OUT;
+    static constexpr int OFF_MZ = OFF_CTX + 4 * 2 * 2048;     // [head][m|z][wave 8][32] floats
+    static constexpr int LDS_BYTES = OFF_MZ + 4 * 2 * 8 * 32 * 4;         // 155648 (C = 64 and C = 128)
+    static_assert(!SHARED || 4 * KS * 2048 + 4 * HEAD_OUT <= A_BYTES, "phase-2 weights must fit region A");
+};
 namespace l3 {
-constexpr int C = 64, KS = C / 16, NTC = C / 32;
-constexpr int HEAD_QKV = 3 * KS * 2048;            // global image: [head][q|k|v][ks][plane][1 KB]   (pack_tattn3 layout)
-constexpr int HEAD_OUT = NTC * 2 * 2048;           // global image: [head][nt][s][plane][1 KB]
-constexpr int A_BYTES = 4 * 2 * KS * 2048;         // 64 KB: [head][k|v][ks][plane][1 KB]
-constexpr int OFF_WQ = A_BYTES, OFF_WO = OFF_WQ + 4 * KS * 2048, OFF_CTX = OFF_WO + 4 * HEAD_OUT;
-constexpr int OFF_MZ = OFF_CTX + 4 * 2 * 2048;     // [head][m|z][wave 8][32] floats
-constexpr int LDS_BYTES = OFF_MZ + 4 * 2 * 8 * 32 * 4;         // 155648
 constexpr float SX = 16.f, SWGT = 4096.f, PROJ_DESCALE = 1.f / (SX * SWGT);
 constexpr float SP = 1024.f, SV = 16.f, SC = 16.f, SQ = 4096.f, SO = 16.f;
 }  // namespace l3
 
 __device__ __forceinline__ int rowmap_l3(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
+template <int C_>
 __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const unsigned char* __restrict__ wq3,
                                                         const unsigned char* __restrict__ wo3) {
     using namespace l3;
+    using G = L3<C_>;
+    constexpr int C = G::C, KS = G::KS, NTC = G::NTC, HEAD_QKV = G::HEAD_QKV, HEAD_OUT = G::HEAD_OUT, A_BYTES = G::A_BYTES;
+    constexpr int OFF_WQ = G::OFF_WQ, OFF_WO = G::OFF_WO, OFF_CTX = G::OFF_CTX, OFF_MZ = G::OFF_MZ;
+    constexpr bool SHARED = G::SHARED, PREFETCH = C == 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int loff = l31 * 32 + hh * 16;
@@ -47,11 +61,15 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
         const int hd = q / (2 * KS * 128), r = q % (2 * KS * 128);
         reinterpret_cast<uint4*>(sm)[q] = reinterpret_cast<const uint4*>(wq3 + (size_t)hd * HEAD_QKV + KS * 2048)[r];
     }
-    for (int q = tid; q < 4 * KS * 128; q += 512) {            // q part of each head: 8 KB per head
-        const int hd = q / (KS * 128), r = q % (KS * 128);
-        reinterpret_cast<uint4*>(sm + OFF_WQ)[q] = reinterpret_cast<const uint4*>(wq3 + (size_t)hd * HEAD_QKV)[r];
-    }
-    for (int q = tid; q < 4 * HEAD_OUT / 16; q += 512) reinterpret_cast<uint4*>(sm + OFF_WO)[q] = reinterpret_cast<const uint4*>(wo3)[q];
+    auto fill_phase2 = [&]() {
+        for (int q = tid; q < 4 * KS * 128; q += 512) {        // q part of each head
+            const int hd = q / (KS * 128), r = q % (KS * 128);
+            reinterpret_cast<uint4*>(sm + OFF_WQ)[q] = reinterpret_cast<const uint4*>(wq3 + (size_t)hd * HEAD_QKV)[r];
+        }
+        for (int q = tid; q < 4 * HEAD_OUT / 16; q += 512)
+            reinterpret_cast<uint4*>(sm + OFF_WO)[q] = reinterpret_cast<const uint4*>(wo3)[q];
+    };
+    if (!SHARED) fill_phase2();
     __syncthreads();
 
     // rows of a tile: lane (token l31, half hh) holds channels 16ks + 8hh .. +7 of k-step ks
@@ -112,11 +130,12 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
 #pragma unroll
             for (int r = 0; r < 16; ++r) ctxT[hd][r] = 0.f;
         }
-        if (wave < ntiles) load_rows(wave);
+        if (PREFETCH && wave < ntiles) load_rows(wave);
         for (int t = wave; t < ntiles; t += 8) {
             f16x8 xs[KS][2];
+            if (!PREFETCH) load_rows(t);
             ln_split(t, xs);
-            if (t + 8 < ntiles) load_rows(t + 8);
+            if (PREFETCH && t + 8 < ntiles) load_rows(t + 8);
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int hd = 0; hd < 4; ++hd) {
@@ -211,15 +230,20 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             }
         }
         __syncthreads();
+        if (SHARED) {                 // the merge scratch is dead: bring in the phase-2 weights
+            fill_phase2();
+            __syncthreads();
+        }
     }
 
     // ================= phase 2: outputs =================
     const float qscale = 0.17677669529663687f;
-    if (wave < ntiles) load_rows(wave);
+    if (PREFETCH && wave < ntiles) load_rows(wave);
     for (int t = wave; t < ntiles; t += 8) {
         f16x8 xs[KS][2];
+        if (!PREFETCH) load_rows(t);
         ln_split(t, xs);
-        if (t + 8 < ntiles) load_rows(t + 8);
+        if (PREFETCH && t + 8 < ntiles) load_rows(t + 8);
         asm volatile("" ::: "memory");
         f32x16 y[NTC];
 #pragma unroll
@@ -301,10 +325,11 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
     }
 }
 
-bool lattn3_supported(int C, int heads) { return C == 64 && heads == 4; }
+bool lattn3_supported(int C, int heads) { return (C == 64 || C == 128) && heads == 4; }
 
-int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned char* wo3, hipStream_t s) {
+int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, hipStream_t s) {
     using namespace l3;
+    DPC_REQUIRE(lattn3_supported(C, 4), "lattn3: unsupported width");
     if (p.images == 0) return DPC_OK;
     DPC_REQUIRE(p.images < (1ll << 31), "lattn3: grid too large");
     const double rows = (double)p.images * p.N;
@@ -312,10 +337,12 @@ int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned
                    4.0 * rows * C * 3, s);
     static bool once = false;
     if (!once) {
-        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<64>::LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<128>::LDS_BYTES));
         once = true;
     }
-    hipLaunchKernelGGL(lattn3_kernel, dim3((unsigned)p.images), dim3(512), LDS_BYTES, s, p, wq3, wo3);
+    if (C == 64) hipLaunchKernelGGL(lattn3_kernel<64>, dim3((unsigned)p.images), dim3(512), L3<64>::LDS_BYTES, s, p, wq3, wo3);
+    else hipLaunchKernelGGL(lattn3_kernel<128>, dim3((unsigned)p.images), dim3(512), L3<128>::LDS_BYTES, s, p, wq3, wo3);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

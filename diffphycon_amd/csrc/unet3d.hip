@@ -319,7 +319,7 @@ struct Runner {
             lp.images = (long long)mb * F; lp.N = Hl * Wl;
             const float* q3 = raw(p + ".fn.fn.to_qkv.weight#h3");
             const float* o3 = raw(p + ".fn.fn.to_out.weight#h3");
-            RUN(launch_lattn3(lp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), s));
+            RUN(launch_lattn3(lp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), C, s));
             return;
         }
         if (h->fused_attn && lattn_fused_supported(C, h->cfg.attn_heads)) {
