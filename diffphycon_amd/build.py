@@ -28,10 +28,11 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("DPC_EXTRA_FLAGS", "").split()       # e.g. -DDPC_CONV_STAMPS for tools/conv_stamps.py
     objs, procs = [], []
     for src in sources():
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

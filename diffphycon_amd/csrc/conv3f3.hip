@@ -311,10 +311,19 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     const int f0 = (t % ntf) * TF;
     const int b = t / ntf;
     const int K = p.C0 + p.C1;
+#ifdef DPC_CONV_STAMPS
+    unsigned long long tstamp[16];
+    int nstamp = 0;
+    auto stamp = [&]() { if (nstamp < 16) tstamp[nstamp++] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
 
-    // halo bookkeeping kept small (the accumulators own most of the register file): a validity bit mask, and the point
-    // index relative to the sample as a 32-bit offset (the LDS slot is recomputed where it is needed)
+    // halo bookkeeping: a validity bit mask, the point index relative to the sample (32-bit) and the LDS slot per quad.
+    // (Recomputing the two index arrays at every chunk cost 1-2 k cycles of MFMA-idle address arithmetic per chunk.)
     unsigned hokm = 0;
+    int hpt[HLOADS], hdst[HLOADS];
     const float* xb0 = p.a0 + (long long)b * p.F * p.H * p.W * p.C0;
     const float* xb1 = p.a1 ? p.a1 + (long long)b * p.F * p.H * p.W * p.C1 : nullptr;
 #pragma unroll
@@ -323,17 +332,10 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
         const int pf = pt / (HH8 * HWL), ph = (pt / HWL) % HH8, pw = pt % HWL;
         const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
         if (pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) hokm |= 1u << i;
+        hpt[i] = (f * p.H + h) * p.W + w;
+        hdst[i] = ((pt / HWL) * HWD + pt % HWL) * PST + ((tid + 256 * i) & 3) * 8;          // + plane*32
     }
-    auto hpt_of = [&](int i) {
-        const int pt = (tid + 256 * i) >> 2;
-        const int pf = pt / (HH8 * HWL), ph = (pt / HWL) % HH8, pw = pt % HWL;
-        return ((f0 - 1 + pf) * p.H + (h0 - 1 + ph)) * p.W + (w0 - 1 + pw);
-    };
     const int hslot = (tid & 3) * 4;
-    auto hdst_of = [&](int i) {
-        const int q = tid + 256 * i, pt = q >> 2;
-        return ((pt / HWL) * HWD + pt % HWL) * PST + (q & 3) * 8;          // + plane*32
-    };
 
     f32x4 hreg[HLOADS];
     uint4 hpk[HLOADS];
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && ((hokm >> i) & 1)) v = *reinterpret_cast<const f32x4*>(src + (long long)hpt_of(i) * cs + cc);
+            if (cok && ((hokm >> i) & 1)) v = *reinterpret_cast<const f32x4*>(src + (long long)hpt[i] * cs + cc);
             hreg[i] = v;
         }
     };
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             if (tid + 256 * i < NLOG * 4) {
-                const int d = hdst_of(i);
+                const int d = hdst[i];
                 *reinterpret_cast<uint2*>(halo + d) = uint2{hpk[i].x, hpk[i].y};
                 *reinterpret_cast<uint2*>(halo + d + 32) = uint2{hpk[i].z, hpk[i].w};
             }
@@ -434,6 +436,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     store_halo();
     __syncthreads();
     lda(0, a[0]);
+    stamp();                                   // 1: prologue
     for (int kc = 0; kc < p.kchunks; ++kc) {
         const bool more_kc = kc + 1 < p.kchunks;
         auto tap_body = [&](int tap) {
@@ -461,18 +464,24 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
         // the next chunk's halo loads go BEHIND the tap-0 weight prefetch: vmcnt retires in order, so every weight load issued
         // after them also waits for them -- this way the first such load is needed three taps (2300 cycles) later
         tap_body(0);
+        if (kc < 2) stamp();                   // tap 0
         if (more_kc) load_halo(kc + 1);
         asm volatile("" ::: "memory");
+        if (kc < 2) stamp();                   // halo issue
 #pragma unroll
         for (int tap = 1; tap < 12; ++tap) tap_body(tap);
+        if (kc < 2) stamp();                   // taps 1..11
         if (more_kc) prepare_halo(kc + 1);
+        if (kc < 2) stamp();                   // prepare
 #pragma unroll
         for (int tap = 12; tap < 27; ++tap) tap_body(tap);
+        if (kc < 2) stamp();                   // taps 12..26
         if (more_kc) {
             __syncthreads();
             store_halo();
             __syncthreads();
             lda(0, a[0]);
+            if (kc < 2) stamp();               // hand-over
         }
     }
 
@@ -517,6 +526,10 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
             }
         }
     }
+#ifdef DPC_CONV_STAMPS
+    if (lane == 0)
+        for (int i = 1; i < nstamp; ++i) p.out[((long long)blockIdx.x * 4 + wave) * 16 + i] = (float)(tstamp[i] - tstamp[i - 1]);
+#endif
 }
 
 // which tiling a launch uses: 0 = (2 x 2)-accumulator kernel on 4x4x8 tiles, 1 = 8x4x8 tiles (64-wide), 2 = big-tile kernel

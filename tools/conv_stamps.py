@@ -1,5 +1,6 @@
-"""Pipeline-stage cycle stamps of the big-tile conv kernel (DPC_CONV_DBG=64): mean cycles per stage over all waves.
-    DPC_CONV_DBG=64 python tools/conv_stamps.py"""
+"""Pipeline-stage cycle stamps (s_memtime) of the big-tile conv kernel: mean cycles per stage over all waves.
+Needs a library built with -DDPC_CONV_STAMPS (the stamps overwrite the start of the output):
+    DPC_EXTRA_FLAGS=-DDPC_CONV_STAMPS python -m diffphycon_amd.build && python tools/conv_stamps.py"""
 import ctypes as C
 import os
 import sys
@@ -26,9 +27,8 @@ for (B, Fr, H, W, Ci, Co) in [(8, 32, 64, 64, 64, 64), (8, 32, 32, 32, 128, 128)
     wide = Co > 64
     tf = 4 if wide else 8
     nwg = B * (Fr // tf) * (H // 8) * (W // 8) * (Co // (128 if wide else 64))
-    kch = Ci // 16
-    n = min(2 + 2 * kch, 12)
+    names = ["prologue"] + [f"{nm}{c}" for c in range(2) for nm in ("tap0_", "halo_issue", "taps1-11_", "prepare", "taps12-26_", "handover")]
+    n = len(names) + 1
     t = out.flatten()[: nwg * 4 * 16].view(nwg * 4, 16)[:, 1:n].double()
-    names = ["prologue"] + [("taps%d" % (i // 2)) if i % 2 == 0 else ("hand%d" % (i // 2)) for i in range(n - 2)]
     mean = t.mean(0).tolist()
-    print(f"{Ci}->{Co} @{H}: ideal taps = {27 * 24 * 32} cycles/chunk;", "  ".join(f"{nm} {v:.0f}" for nm, v in zip(names, mean)))
+    print(f"{Ci}->{Co} @{H}: ideal = {24 * 32} cycles/tap;", "  ".join(f"{nm} {v:.0f}" for nm, v in zip(names, mean)))
