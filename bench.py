@@ -312,6 +312,7 @@ def main():
         t_cur -= 1
         sync()
         log("warmup step done")
+    sync()                                   # barrier + device sync on both sides of the timed region (also when --warmup 0)
     _lib.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
