@@ -206,11 +206,21 @@ def main_burgers(args, rank, world, device, dist):
             torch.cuda.synchronize()
 
     t_cur = 999
-    for _ in range(args.warmup):
+    prof_all = None
+    for i in range(args.warmup):
+        last = i == args.warmup - 1
+        if last:
+            _lib.profile_begin()             # every class on an untimed step (see main())
+        tw0 = time.perf_counter()
         step(t_cur)
         t_cur -= 1
         sync()
-    _lib.profile_begin()
+        warm_ms = (time.perf_counter() - tw0) * 1e3
+        if last:
+            prof_all = _lib.profile_end()
+    sync()
+    dom_name = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else None
+    _lib.profile_begin([dom_name] if dom_name else None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(t_cur)
@@ -234,8 +244,11 @@ def main_burgers(args, rank, world, device, dist):
                 {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0})
         roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": d["launches"],
                      "avg_launch_ms": d["total_ms"] / max(d["launches"], 1),
-                     "breakdown_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
-                     "kernel_time_fraction_of_step": sum(v["total_ms"] for v in prof.values()) / (elapsed * 1e3),
+                     "breakdown_ms_per_step": ({k: round(v["total_ms"], 3) for k, v in sorted(prof_all.items())} if prof_all else
+                                               {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())}),
+                     "breakdown_note": "all classes on the last untimed warm-up step; timed steps bracket the roofline class only",
+                     "kernel_time_fraction_of_step": (sum(v["total_ms"] for v in prof_all.values()) / warm_ms if prof_all else
+                                                      sum(v["total_ms"] for v in prof.values()) / (elapsed * 1e3)),
                      "step_flops_fraction_of_fp32_peak": (B * 15.8 / 1e3 / sec) / PEAK_FP32_MFMA_TFLOPS})
         out = {"metric": "guided trajectories/sec, 1D Burgers POPC 128 cells x 10 steps @1000 DDPM steps",
                "value": world * B / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": world,
@@ -307,13 +320,24 @@ def main():
 
     t_cur = 999
     log("models built, starting warmup")
-    for _ in range(args.warmup):
+    prof_all = None
+    for i in range(args.warmup):
+        last = i == args.warmup - 1
+        if last:
+            _lib.profile_begin()             # every kernel class, on an UNTIMED step: per-class breakdown + dominant class
+        tw0 = time.perf_counter()
         step(t_cur)
         t_cur -= 1
         sync()
+        warm_ms = (time.perf_counter() - tw0) * 1e3
+        if last:
+            prof_all = _lib.profile_end()
         log("warmup step done")
     sync()                                   # barrier + device sync on both sides of the timed region (also when --warmup 0)
-    _lib.profile_begin()
+    # Two HIP events per launch cost ~4 % of the step when every launch is bracketed (tools/profile_overhead.py), so the
+    # timed steps instrument only the dominant kernel class (the roofline kernel); the other classes come from the warm-up pass.
+    dom_name = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else None
+    _lib.profile_begin([dom_name] if dom_name else None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(t_cur)
@@ -347,9 +371,14 @@ def main():
         roof["kernel"] = name
         roof["launches"] = d["launches"]
         roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
-        gpu_ms = sum(v["total_ms"] for v in prof.values())
-        roof["breakdown_ms_per_step"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())}
-        roof["kernel_time_fraction_of_step"] = gpu_ms / (elapsed * 1e3)
+        if prof_all:
+            roof["breakdown_ms_per_step"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof_all.items())}
+            roof["breakdown_note"] = ("all classes bracketed by events on the last (untimed) warm-up step; the timed steps bracket "
+                                      "only the roofline kernel class")
+            roof["kernel_time_fraction_of_step"] = sum(v["total_ms"] for v in prof_all.values()) / warm_ms   # of that warm-up step
+        else:
+            roof["breakdown_ms_per_step"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())}
+            roof["kernel_time_fraction_of_step"] = sum(v["total_ms"] for v in prof.values()) / (elapsed * 1e3)
         unit_gflop = 1794.5        # algorithmic GFLOP per trajectory-step (both U-Nets)
         roof["step_flops_fraction_of_fp32_peak"] = (B * unit_gflop / 1e3 / sec_per_step) / PEAK_FP32_MFMA_TFLOPS
         out = {

@@ -65,8 +65,12 @@ class ProfileRow(C.Structure):
                 ("bytes", C.c_double)]
 
 
-def profile_begin():
-    check(lib().dpc_profile_begin())
+def profile_begin(classes=None):
+    """Start per-class event timing; `classes` (iterable of class names) restricts the instrumentation."""
+    if classes:
+        check(lib().dpc_profile_begin_classes(",".join(classes).encode()))
+    else:
+        check(lib().dpc_profile_begin())
 
 
 def profile_end():
@@ -84,6 +88,7 @@ _SIGNATURES = {
     "dpc_version": (C.c_int, []),
     "dpc_last_error": (C.c_char_p, []),
     "dpc_profile_begin": (C.c_int, []),
+    "dpc_profile_begin_classes": (C.c_int, [C.c_char_p]),
     "dpc_profile_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dpc_unet3d_create": (C.c_int, [C.POINTER(Unet3DCfg), C.POINTER(_P)]),
     "dpc_unet3d_destroy": (None, [_P]),

@@ -1,6 +1,7 @@
 // Opt-in per-kernel-class timing with HIP events recorded on the launch stream (bench.py's roofline leg).
 // Disabled by default: a disabled ProfScope costs one branch and records nothing.
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -15,6 +16,7 @@ static const char* kClassNames[PROF_NCLASS] = {
 
 struct ProfState {
     bool on = false;
+    unsigned long long mask = ~0ull;         // classes that are instrumented
     struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -33,7 +35,7 @@ static hipEvent_t prof_event() {
 }
 
 ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : idx_(-1), s_(s) {
-    if (!g_prof.on) return;
+    if (!g_prof.on || !((g_prof.mask >> cls) & 1ull)) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (g_prof.recs.size() >= (1u << 20)) return;
     hipEvent_t a = prof_event(), b = prof_event();
@@ -55,10 +57,22 @@ using namespace dpc;
 
 extern "C" {
 
-int dpc_profile_begin(void) {
+int dpc_profile_begin(void) { return dpc_profile_begin_classes(nullptr); }
+
+int dpc_profile_begin_classes(const char* class_names) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
+    unsigned long long mask = 0;
+    if (class_names && class_names[0]) {
+        const std::string all = std::string(",") + class_names + ",";
+        for (int i = 0; i < PROF_NCLASS; ++i)
+            if (all.find(std::string(",") + kClassNames[i] + ",") != std::string::npos) mask |= 1ull << i;
+        DPC_REQUIRE(mask != 0, "profile_begin_classes: no known class name in '" + std::string(class_names) + "'");
+    } else {
+        mask = ~0ull;
+    }
     g_prof.recs.clear();
     g_prof.pool_next = 0;
+    g_prof.mask = mask;
     g_prof.on = true;
     return DPC_OK;
 }
