@@ -73,6 +73,10 @@ struct IgemmParams {
     int par_a, par_b;
     signed char tdf[32], tdh[32], tdw[32];
     long long M;
+    // split-K (igemm3 only, set by its launcher): blockIdx.y = slice of the (tap, channel-chunk) iterations; raw accumulators go
+    // to part[slice][M][N] and a second kernel adds the slices in fixed order, rescales and applies bias / residual
+    int ksplit;
+    float* part;
 };
 int igemm_npad(int N);
 int igemm_kchunks(int K);

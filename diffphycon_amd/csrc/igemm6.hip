@@ -350,15 +350,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const int a_lane = (wm * 64 + l31) * RS + hh * 16;
-    const int niter = p.ntaps * p.kchunks;
-    load_a(0);
-    ldw(0, wc);
+    // split-K: this workgroup owns iterations [it0, niter) of the (tap, channel-chunk) sequence
+    const int nit_all = p.ntaps * p.kchunks;
+    const int nsl = p.ksplit > 1 ? p.ksplit : 1;
+    const int it0 = (int)((long long)nit_all * blockIdx.y / nsl), niter = (int)((long long)nit_all * (blockIdx.y + 1) / nsl);
+    load_a(it0);
+    ldw(it0, wc);
     store_a(As0);
     __syncthreads();
-    for (int it = 0; it < niter; ++it) {
+    for (int it = it0; it < niter; ++it) {
         const bool more = it + 1 < niter;
         if (more) { load_a(it + 1); ldw(it + 1, wx); }
-        const unsigned char* As = (it & 1) ? As1 : As0;
+        const unsigned char* As = ((it - it0) & 1) ? As1 : As0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8_g a[2][2];
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], wc[ks][nt][PB[term]], acc[mt][nt], 0, 0, 0);
         }
         if (more) {
-            store_a((it & 1) ? As0 : As1);
+            store_a(((it - it0) & 1) ? As0 : As1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -389,6 +392,22 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
     }
     // ---- epilogue (accumulator layout and output modes of igemm.hip).  Row-major loop: the output row offset -- two integer
     //      divisions in the channel-first and ConvTranspose-parity modes -- is computed once per accumulator row, not per element
+    if (p.ksplit > 1) {        // raw partial accumulators, [slice][M][N]; finished by igemm3_reduce_kernel
+        float* pb = p.part + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + wn * (BN / 2) + nt * 32 + l31;
+                    if (n < p.N) pb[m * p.N + n] = acc[mt][nt][r];
+                }
+            }
+        return;
+    }
     float bv[NT];
     int ncol[NT];
 #pragma unroll
@@ -426,6 +445,20 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
     }
 }
 
+// second half of a split-K launch: out = (sum of the slices in index order) * 2^-16 + bias (+ residual), [M][N] layout
+__global__ __launch_bounds__(256) void igemm3_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                            const float* __restrict__ resid, float* __restrict__ out, long long MN,
+                                                            int N, int nsl) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
+    for (int s = 1; s < nsl; ++s) v += *reinterpret_cast<const f32x4*>(part + (long long)s * MN + i);
+    v *= g3::DESCALE;
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int)(i % N));
+    if (resid) v += *reinterpret_cast<const f32x4*>(resid + i);
+    *reinterpret_cast<f32x4*>(out + i) = v;
+}
+
 int igemm_mode_default() {
     static const int mode = [] {
         const char* e = getenv("DPC_IGEMM_MODE");
@@ -460,6 +493,36 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
     ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
     if (igemm_mode_default() == 2) {
         const size_t lds3 = 2 * (size_t)g3::BM * g3::RS;
+        // split-K for the GEMM-shaped deep levels of the 2-D U-Net (K x taps >= 4096: few row tiles, hundreds of iterations;
+        // 256 workgroups leave three quarters of the 4-per-CU slots empty): four slices of the iteration range run as
+        // separate workgroups, a second kernel adds them in fixed order.  The rule looks at the reduction length only, never
+        // at the batch, so a trajectory's result does not depend on how the batch is sharded or micro-batched.  The scratch
+        // buffer is grown on first use (warm-up), never inside a steady-state step.
+        static const int split_ok = [] { const char* e = getenv("DPC_IGEMM_SPLITK"); return e ? atoi(e) : 1; }();
+        const long long nwg = (long long)mtiles * (p.Npad / 64);
+        const int nit = p.ntaps * p.kchunks;
+        int nsl = 1;
+        if (split_ok && !wide && p.out_mode == 0 && !p.ln_stats && p.N % 4 == 0 && nit >= 128) nsl = 4;
+        if (nsl > 1) {
+            static float* scratch = nullptr;
+            static size_t cap = 0;
+            const size_t need = (size_t)nsl * p.M * p.N * sizeof(float);
+            if (need > cap) {
+                if (scratch) (void)hipFree(scratch);
+                DPC_HIP(hipMalloc(&scratch, need));
+                cap = need;
+            }
+            IgemmParams q = p;
+            q.ksplit = nsl;
+            q.part = scratch;
+            hipLaunchKernelGGL(igemm3_kernel<64>, dim3((unsigned)nwg, nsl), dim3(256), lds3, s, q, (const unsigned char*)wp6);
+            DPC_LAUNCH_CHECK();
+            const long long MN = p.M * p.N;
+            hipLaunchKernelGGL(igemm3_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, scratch, p.bias, p.resid,
+                               p.out, MN, p.N, nsl);
+            DPC_LAUNCH_CHECK();
+            return DPC_OK;
+        }
         if (wide) {
             hipLaunchKernelGGL(igemm3_kernel<128>, dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
         } else {
