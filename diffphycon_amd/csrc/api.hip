@@ -107,6 +107,16 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
         if (rc) return rc;
         return launch_conv3h(q, s);
     }
+    if (kd == 1 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pd == 0 && ph == 1 && pw == 1 && conv_mode_default() == 2 &&
+        H % 8 == 0 && W % 8 == 0 && Cin % 4 == 0) {
+        // (1,3,3): the big-tile halo kernel with the frames as independent images (the 2-D U-Net's 3x3 convs)
+        Conv3hParams q{};
+        q.a0 = x_cl; q.C0 = Cin; q.wp = wp; q.bias = bias; q.out = out_cl;
+        q.B = 1; q.F = B * F; q.H = H; q.W = W; q.N = Cout; q.Npad = p.Npad; q.kchunks = (Cin + 15) / 16; q.kd = 1;
+        int rc = launch_pack_weights_f3(w_ref, wp, Cout, p.Npad, Cin, s, 9);
+        if (rc) return rc;
+        return launch_conv3f3(q, s);
+    }
     const bool x6 = igemm_mode_default() >= 1;
     int rc = x6 ? launch_pack_weights_g6(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s)
                 : launch_pack_weights(w_ref, wp, Cout, p.Npad, Cin, ntaps, (long long)Cin * ntaps, ntaps, off, s);

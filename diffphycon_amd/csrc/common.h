@@ -102,6 +102,7 @@ struct Conv3hParams {
     int B, F, H, W;
     int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
     int dbg;                // perf attribution only (env DPC_CONV_DBG): 1 skip output stores, 2 skip halo loads, 4 skip weight loads
+    int kd;                 // 0 / 3: 3x3x3 kernel; 1: (1,3,3) kernel over independent frames (conv3f3 big-tile kernel only)
     // GroupNorm fusion (conv3x6 only):
     float* gn_part;         // out: per-(sample, tile, frame-pair) channel sums of the conv output [B][tiles][2][N][2] (sum, sum sq)
     const float* in_coef;   // in: GroupNorm+scale/shift coefficients of the INPUT [B][K/4][5][4] (mu, rstd*gamma, beta, scale+1,
@@ -124,7 +125,7 @@ int launch_conv3x6(const Conv3hParams& p, hipStream_t s);
 int launch_pack_weights_x6(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
 // same op with a 2-way fp16 split (22-bit operands, 3 MFMAs per product; conv3f3.hip); p.wp = [27][kchunks][Npad][2][16] fp16
 int launch_conv3f3(const Conv3hParams& p, hipStream_t s);
-int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
+int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s, int ntaps = 27);   // 9: (1,3,3) kernel
 long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad);     // GroupNorm partial-sum entries per (sample, channel)
 // 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6), 2: f16x3 split (conv3f3); env DPC_CONV_MODE=f32|x6|f16x3, default f16x3
 int conv_mode_default();

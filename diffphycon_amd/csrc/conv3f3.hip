@@ -285,11 +285,14 @@ using namespace f3;
 constexpr int TH8 = 8, HH8 = TH8 + 2;
 }
 
-template <int BN>
+// KD = 3: the 3x3x3 convolution.  KD = 1: a (1,3,3) convolution -- the 2-D U-Net's 3x3 convs with the batch on the frame
+// axis (no coupling between frames: 9 taps, no frame halo).  Partial frame tiles are allowed (F need not divide), so the
+// kernel choice never depends on the batch size.
+template <int BN, int KD>
 __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     using namespace f3b;
     constexpr int WM = BN == 64 ? 4 : 2, WN = 4 / WM, MT = 4, NT = 2;
-    constexpr int TF = 2 * WM, HF = TF + 2;
+    constexpr int TF = 2 * WM, HF = TF + KD - 1, NTAPS = 9 * KD, FPAD = KD / 2;
     constexpr int NLOG = HF * HH8 * HWL;               // 1000 / 600 halo points
     constexpr int HLOADS = (NLOG * 4 + 255) / 256;     // 16 / 10
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3b[];
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     for (int i = 0; i < HLOADS; ++i) {
         const int pt = (tid + 256 * i) >> 2;
         const int pf = pt / (HH8 * HWL), ph = (pt / HWL) % HH8, pw = pt % HWL;
-        const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
+        const int f = f0 - FPAD + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
         if (pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) hokm |= 1u << i;
         hpt[i] = (f * p.H + h) * p.W + w;
         hdst[i] = ((pt / HWL) * HWD + pt % HWL) * PST + ((tid + 256 * i) & 3) * 8;          // + plane*32
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     int wtap_i = 0, wkc_i = 0;
     auto ldw = [&](int, int, f16x8 (&dst)[NT][2]) {
         const unsigned char* src = wnext;
-        if (++wtap_i == 27) { wtap_i = 0; ++wkc_i; wnext = wlane + wkc_i * wstride; }
+        if (++wtap_i == NTAPS) { wtap_i = 0; ++wkc_i; wnext = wlane + wkc_i * wstride; }
         else wnext += wtap;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
             for (int pl = 0; pl < 2; ++pl) dst[nt][pl] = *reinterpret_cast<const f16x8*>(src + nt * 32 * WROW + pl * 32);
     };
     auto lda = [&](int tap, f16x8 (&dst)[MT][2]) {
-        const int df = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int df = KD == 3 ? tap / 9 : 0, dh = (tap / 3) % 3, dw = tap % 3;
         const int aoff = a_lane + ((df * HH8 + dh) * HWD + dw) * PST;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -441,9 +444,9 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
         const bool more_kc = kc + 1 < p.kchunks;
         auto tap_body = [&](int tap) {
             const int tw = tap + 2;
-            if (tw < 27) ldw(tw, kc, w[tw % 3]);
-            else if (more_kc) ldw(tw - 27, kc + 1, w[tw % 3]);
-            if (tap < 26) lda(tap + 1, a[(tap + 1) & 1]);
+            if (tw < NTAPS) ldw(tw, kc, w[tw % 3]);
+            else if (more_kc) ldw(tw - NTAPS, kc + 1, w[tw % 3]);
+            if (tap < NTAPS - 1) lda(tap + 1, a[(tap + 1) & 1]);
             // pin the prefetches HERE: without the scheduling barrier the compiler hoists this tap's MFMAs above them (they are
             // not memory operations), which leaves every load right in front of its first use -- no prefetch distance at all
             asm volatile("" ::: "memory");
@@ -469,12 +472,12 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
         asm volatile("" ::: "memory");
         if (kc < 2) stamp();                   // halo issue
 #pragma unroll
-        for (int tap = 1; tap < 12; ++tap) tap_body(tap);
+        for (int tap = 1; tap < NTAPS / 2; ++tap) tap_body(tap);
         if (kc < 2) stamp();                   // taps 1..11
         if (more_kc) prepare_halo(kc + 1);
         if (kc < 2) stamp();                   // prepare
 #pragma unroll
-        for (int tap = 12; tap < 27; ++tap) tap_body(tap);
+        for (int tap = NTAPS / 2; tap < NTAPS; ++tap) tap_body(tap);
         if (kc < 2) stamp();                   // taps 12..26
         if (more_kc) {
             __syncthreads();
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
         }
     }
 
-    // ---- epilogue: the launcher guarantees full tiles (F % TF == 0, H % 8 == 0, W % 8 == 0), so a slab's 32 points are a
+    // ---- epilogue: the launcher guarantees full tiles in H and W (H % 8 == 0, W % 8 == 0; frames are checked per slab), so a slab's 32 points are a
     //      fixed per-lane offset pattern from one base pointer (no bounds checks, no 64-bit address arithmetic per store)
     int poff[16];
 #pragma unroll
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int f = f0 + wm * 2 + (mt >> 1), h = h0 + 4 * (mt & 1);
+                if (f >= p.F) continue;              // partial frame tile
                 float* base = p.out + ((((long long)b * p.F + f) * p.H + h) * p.W + w0) * p.N + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -537,7 +541,7 @@ static int conv3f3_variant(int F, int H, int W, int N, int Npad) {
     static const int big_ok = [] { const char* e = getenv("DPC_CONV3F3_BIG"); return e ? atoi(e) : 1; }();
     static const int tall_ok = [] { const char* e = getenv("DPC_CONV3F3_TALL"); return e ? atoi(e) : 1; }();
     const bool wide = Npad % 128 == 0 && N > 64;
-    if (big_ok && F % (wide ? 4 : 8) == 0 && H % 8 == 0 && W % 8 == 0) return 2;
+    if (big_ok && H % 8 == 0 && W % 8 == 0 && (F % (wide ? 4 : 8) == 0 || F >= 16)) return 2;       // partial frame tiles: F >= 16 only
     if (!wide && tall_ok && F % 8 == 0) return 1;
     return 0;
 }
@@ -549,7 +553,7 @@ long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad) {
     const int v = conv3f3_variant(F, H, W, N, Npad);
     if (v == 2) {
         const int tf = wide ? 4 : 8;
-        return (long long)(F / tf) * (H / 8) * (W / 8) * (wide ? 2 : 4);
+        return (long long)((F + tf - 1) / tf) * (H / 8) * (W / 8) * (wide ? 2 : 4);
     }
     const int tf = v == 1 ? 8 : 4;
     return (long long)((F + tf - 1) / tf) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * (tf / 2);
@@ -562,28 +566,38 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     DPC_REQUIRE(!(p.in_coef && p.C1 != 0), "conv3f3: fused input normalisation needs a single source");
     if (p.B == 0) return DPC_OK;
     const double M = (double)p.B * p.F * p.H * p.W;
-    const double flops = 2.0 * M * p.N * 27.0 * (p.C0 + p.C1);
-    const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
+    const double ntap = p.kd == 1 ? 9.0 : 27.0;
+    const double flops = 2.0 * M * p.N * ntap * (p.C0 + p.C1);
+    const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + ntap * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
     Conv3hParams pd = p;
     pd.dbg = dbg;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
-    const int variant = conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
+    const bool flat = p.kd == 1;                 // (1,3,3) convolution: big-tile kernel only
+    DPC_REQUIRE(!flat || (p.H % 8 == 0 && p.W % 8 == 0), "conv3f3: the (1,3,3) form needs H % 8 == 0 and W % 8 == 0");
+    const int variant = flat ? 2 : conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
     if (variant == 2) {
         const int tf = wide ? 4 : 8;
-        const long long tiles = (long long)p.B * (p.F / tf) * (p.H / 8) * (p.W / 8);
+        const long long tiles = (long long)p.B * ((p.F + tf - 1) / tf) * (p.H / 8) * (p.W / 8);
         const long long grid = tiles * (p.Npad / (wide ? 128 : 64));
         DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
-        const size_t lds = (size_t)(tf + 2) * f3b::HH8 * HWD * PST;
+        const size_t lds = (size_t)(tf + (flat ? 0 : 2)) * f3b::HH8 * HWD * PST;
         static bool once = false;
         if (!once) {
-            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 12 * PST));
-            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 10 * 12 * PST));
             once = true;
         }
-        if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128>), dim3((unsigned)grid), dim3(256), lds, s, pd);
-        else hipLaunchKernelGGL((conv3f3b_kernel<64>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        if (flat) {
+            if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128, 1>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+            else hipLaunchKernelGGL((conv3f3b_kernel<64, 1>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        } else {
+            if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128, 3>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+            else hipLaunchKernelGGL((conv3f3b_kernel<64, 3>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+        }
         DPC_LAUNCH_CHECK();
         return DPC_OK;
     }
@@ -609,8 +623,8 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
 
 // ---- weight pre-split: reference [N][K][3][3][3] fp32 -> [27][kchunks][Npad][2 planes][16] fp16 (scaled by 2^12)
 __global__ void pack_weights_f3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int K,
-                                       int kchunks) {
-    const long long total = 27ll * kchunks * Npad * 16;
+                                       int kchunks, int ntaps) {
+    const long long total = (long long)ntaps * kchunks * Npad * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 16);
         long long r = i / 16;
@@ -620,7 +634,7 @@ __global__ void pack_weights_f3_kernel(const float* __restrict__ w, unsigned sho
         const int tap = (int)(r / kchunks);
         const int c = kc * 16 + kk;
         float v = 0.f;
-        if (n < N && c < K) v = f3::sat16(w[((long long)n * K + c) * 27 + tap] * f3::SW);
+        if (n < N && c < K) v = f3::sat16(w[((long long)n * K + c) * ntaps + tap] * f3::SW);
         const unsigned p1 = f3::cvt_pk_f16(v, 0.f) & 0xffffu;
         const float h1 = (float)__builtin_bit_cast(f3::f16x2, p1).x;
         const unsigned p2 = f3::cvt_pk_f16(v - h1, 0.f) & 0xffffu;
@@ -630,12 +644,12 @@ __global__ void pack_weights_f3_kernel(const float* __restrict__ w, unsigned sho
     }
 }
 
-int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s) {
+int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s, int ntaps) {
     const int kchunks = (K + 15) / 16;
-    const long long total = 27ll * kchunks * Npad * 16;
+    const long long total = (long long)ntaps * kchunks * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_f3_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), N, Npad,
-                       K, kchunks);
+                       K, kchunks, ntaps);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -123,7 +123,16 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     if (!pc.halo) {
         if (igemm_mode_default() == 0) return DPC_OK;
         if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, ntaps)))) return rc;
-        return launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s);
+        if ((rc = launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, ntaps, (long long)K * ntaps, ntaps, off, s))) return rc;
+        // the 2-D U-Net's 3x3 convs: 9-tap f16x3 pack for the big-tile halo kernel (taken when H % 8 == 0 and W % 8 == 0)
+        pc.flat3 = kd == 1 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pd == 0 && ph == 1 && pw == 1 && K % 4 == 0 &&
+                   conv_mode_default() == 2;
+        if (pc.flat3) {
+            const int kc16 = (K + 15) / 16;
+            if ((rc = pc.wp3.alloc((size_t)9 * kc16 * pc.Npad * 64))) return rc;
+            return launch_pack_weights_f3(w, pc.wp3.p, N, pc.Npad, K, s, 9);
+        }
+        return DPC_OK;
     }
     if (conv_mode_default() == 2) {
         if ((rc = pc.wp3.alloc((size_t)27 * pc.kchunks * pc.Npad * 64))) return rc;
@@ -177,6 +186,15 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
             return launch_conv3x6(q, s);
         }
         return launch_conv3h(q, s);
+    }
+    static const int flat_ok = [] { const char* e = getenv("DPC_CONV2D_HALO"); return e ? atoi(e) : 1; }();
+    if (flat_ok && pc.flat3 && !resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo && Hi % 8 == 0 && Wi % 8 == 0 &&
+        C0 % 4 == 0 && C1 % 4 == 0) {
+        // (1,3,3) convolution on the halo-tile kernel: frames = the BF images (no coupling), shape-only rule (any batch size)
+        Conv3hParams q{};
+        q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = reinterpret_cast<const float*>(pc.wp3.p); q.bias = bias; q.out = out;
+        q.B = 1; q.F = BF; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = (pc.K + 15) / 16; q.kd = 1;
+        return launch_conv3f3(q, s);
     }
     IgemmParams p{};
     p.a0 = a0; p.a1 = a1; p.C0 = C0; p.C1 = C1;

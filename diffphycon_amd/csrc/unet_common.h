@@ -24,6 +24,7 @@ struct PackedConv {
     DevBuf wp;
     int N = 0, Npad = 0, K = 0, kchunks = 0, ntaps = 0;
     int sh = 1, sw = 1;
+    bool flat3 = false;     // (1,3,3) stride-1 pad-(0,1,1) conv: wp3 also holds the 9-tap f16x3 pack for the big-tile kernel (conv3f3.hip)
     bool halo = false;      // 3x3x3 stride-1 conv: packed with bk = 16 for the LDS halo-tile kernel (conv3h.hip)
     DevBuf wp6;             // ... and pre-split into 3 bf16 planes for the bf16x6 kernel (conv3x6.hip)
     DevBuf wp3;             // ... or into 2 fp16 planes for the f16x3 kernel (conv3f3.hip)

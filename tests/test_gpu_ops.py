@@ -54,6 +54,12 @@ CONV_CASES = [
     (1, 4, 16, 8, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 8, 8, 8, 48, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 16, 8, 8, 20, 40, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 20, 16, 16, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),         # partial frame tile (jellyfish: 20 frames)
+    # (1,3,3): the 2-D U-Net's 3x3 convolutions on the halo kernel, batch on the frame axis (any batch size, partial tiles)
+    (1, 16, 16, 128, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (3, 1, 8, 64, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (5, 1, 16, 24, 12, 72, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (2, 3, 4, 8, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),            # H % 8 != 0: implicit-GEMM path
 ]
 
 
