@@ -9,7 +9,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-// out[b][n] = out_act(bias[n] + sum_k in_act(in[b][k]) W[n][k]).  One wave per (output column n, block of 16 rows b): the
+// out[b][n] = out_act(bias[n] + sum_k in_act(in[b][k]) W[n][k]).  One wave per (output column n, block of BB rows b; BB = 16 for B >= 64): the
 // weight row is read once into registers and reused for the 16 rows (one wave per ELEMENT re-read it B times: 172 us for the
 // 256 x 256 -> 2048 time-embedding projections of the Burgers net).  Per element the arithmetic is unchanged: lane-strided
 // partial sums in ascending k, then the xor butterfly.
@@ -17,8 +17,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 template <int KR>      // K <= 64 * KR
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ in, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                           int B, int K, int N, int in_act, int out_act, int nbb) {
-    constexpr int BB = 16;
+                                                           int B, int K, int N, int in_act, int out_act, int nbb, int BB) {
     const int lane = threadIdx.x & 63;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= (long long)nbb * N) return;
@@ -48,11 +47,12 @@ int launch_small_linear(const float* in, const float* W, const float* bias, floa
     if (total == 0) return DPC_OK;
     DPC_REQUIRE(K <= 2048, "small_linear: K <= 2048");
     ProfScope prof(PROF_SMALL, 2.0 * B * (double)N * K, 4.0 * ((double)N * K + (double)B * (N + K)), s);
-    const int nbb = (B + 15) / 16;
+    const int bb = B >= 64 ? 16 : 1;            // small batches (the 3-D nets' micro-batches): one wave per element is faster
+    const int nbb = (B + bb - 1) / bb;
     const dim3 grid((unsigned)(((long long)nbb * N + 3) / 4)), blk(256);
-    if (K <= 256) hipLaunchKernelGGL(small_linear_kernel<4>, grid, blk, 0, s, in, W, bias, out, B, K, N, in_act, out_act, nbb);
-    else if (K <= 1024) hipLaunchKernelGGL(small_linear_kernel<16>, grid, blk, 0, s, in, W, bias, out, B, K, N, in_act, out_act, nbb);
-    else hipLaunchKernelGGL(small_linear_kernel<32>, grid, blk, 0, s, in, W, bias, out, B, K, N, in_act, out_act, nbb);
+    if (K <= 256) hipLaunchKernelGGL(small_linear_kernel<4>, grid, blk, 0, s, in, W, bias, out, B, K, N, in_act, out_act, nbb, bb);
+    else if (K <= 1024) hipLaunchKernelGGL(small_linear_kernel<16>, grid, blk, 0, s, in, W, bias, out, B, K, N, in_act, out_act, nbb, bb);
+    else hipLaunchKernelGGL(small_linear_kernel<32>, grid, blk, 0, s, in, W, bias, out, B, K, N, in_act, out_act, nbb, bb);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
