@@ -77,6 +77,12 @@ struct IgemmParams {
     // to part[slice][M][N] and a second kernel adds the slices in fixed order, rescales and applies bias / residual
     int ksplit;
     float* part;
+    // fused GroupNorm-apply residual (igemm3, out_mode 0): v += silu((gn_raw[m][n] - mu) * ga + be) with the per-(sample,
+    // channel) coefficients of launch_gn_finalize_fused ([B][N/4][5][4]); gn_rows = rows per sample (multiple of 128).
+    // This is ResnetBlock's  block2(h) + res_conv(x)  without materialising block2's activated output.
+    const float* gn_raw;
+    const float* gn_coef;
+    long long gn_rows;
 };
 int igemm_npad(int N);
 int igemm_kchunks(int K);

@@ -416,6 +416,16 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
         bv[nt] = (ncol[nt] < p.N && p.bias) ? p.bias[ncol[nt]] : 0.f;
     }
     const long long cstride = p.out_mode == 1 ? (long long)HoWo : 1ll;
+    float gmu[NT], gga[NT], gbe[NT];          // fused GroupNorm-apply residual: the tile lies inside one sample
+    if (p.gn_raw) {
+        const long long bsmp = m0 / p.gn_rows;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = ncol[nt] < p.N ? ncol[nt] : 0;
+            const float* cf = p.gn_coef + ((bsmp * (p.N >> 2) + (n >> 2)) * 5) * 4 + (n & 3);
+            gmu[nt] = cf[0]; gga[nt] = cf[4]; gbe[nt] = cf[8];
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -434,11 +444,16 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
                 orow = ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N;
             }
             const float* rrow = p.resid ? p.resid + m * p.N : nullptr;
+            const float* grow = p.gn_raw ? p.gn_raw + m * p.N : nullptr;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (ncol[nt] >= p.N) continue;
                 float v = acc[mt][nt][r] * DESCALE + bv[nt];
                 if (rrow) v += rrow[ncol[nt]];
+                if (grow) {
+                    const float y = (grow[ncol[nt]] - gmu[nt]) * gga[nt] + gbe[nt];
+                    v += y / (1.0f + expf(-y));
+                }
                 p.out[orow + ncol[nt] * cstride] = v;
             }
         }
@@ -502,7 +517,9 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
         const long long nwg = (long long)mtiles * (p.Npad / 64);
         const int nit = p.ntaps * p.kchunks;
         int nsl = 1;
-        if (split_ok && !wide && p.out_mode == 0 && !p.ln_stats && p.N % 4 == 0 && nit >= 128) nsl = 4;
+        if (split_ok && !wide && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && p.N % 4 == 0 && nit >= 128) nsl = 4;
+        DPC_REQUIRE(!p.gn_raw || (p.out_mode == 0 && !wide && p.N % 4 == 0 && p.gn_rows % 128 == 0),
+                    "igemm3: fused GroupNorm residual needs out_mode 0, N % 4 == 0, rows per sample % 128 == 0");
         if (nsl > 1) {
             static float* scratch = nullptr;
             static size_t cap = 0;

@@ -142,6 +142,11 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     return launch_pack_weights_x6(w, pc.wp6.p, N, pc.Npad, K, s);
 }
 
+bool conv_can_fuse_gn_residual(const PackedConv& pc, long long rows_per_sample) {
+    static const int ok = [] { const char* e = getenv("DPC_FUSE_GN_RES"); return e ? atoi(e) : 1; }();
+    return ok && !pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && pc.N % 4 == 0 && rows_per_sample % 128 == 0;
+}
+
 // One output-parity class (a,b) of ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1), weight [K][N][1][4][4]:
 // out[2i+a][2j+b] = sum over the 2x2 taps (dh,kh) x (dw,kw) below of in[i+dh][j+dw] * w[:, :, kh, kw].
 int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b, hipStream_t s) {
@@ -168,8 +173,10 @@ int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
              const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part,
-             const float* in_coef) {
+             const float* in_coef, const float* gn_raw, const float* gn_coef) {
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
+    DPC_REQUIRE(!gn_raw || (!pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && gn_coef),
+                "conv: the fused GroupNorm residual needs the f16x3 implicit GEMM");
     DPC_REQUIRE(!(gn_part || in_coef) || (pc.halo && conv_mode_default() >= 1), "conv: GroupNorm fusion needs the split-operand conv path");
     if (pc.halo) {
         DPC_REQUIRE(!resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo, "conv3h: plain 3x3x3 conv only");
@@ -205,6 +212,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
     p.out_mode = out_mode; p.par_a = par_a; p.par_b = par_b;
     for (int i = 0; i < 32; ++i) { p.tdf[i] = pc.tdf[i]; p.tdh[i] = pc.tdh[i]; p.tdw[i] = pc.tdw[i]; }
     p.M = (long long)BF * Ho * Wo;
+    p.gn_raw = gn_raw; p.gn_coef = gn_coef; p.gn_rows = (long long)F * Ho * Wo;
     if (pc.wp6g.p) return launch_igemm6(p, pc.wp6g.p, s);
     return launch_igemm(p, s);
 }
@@ -299,15 +307,23 @@ struct Runner {
                                              raw(p + ".block1.norm.bias"), ss, stats, coef, s));
                 RUN(run_conv(*c2, raw1, nullptr, Cout, 0, raw(p + ".block2.proj.bias"), nullptr, raw2, mb * F, F, Hl, Wl, Hl, Wl,
                              nullptr, nullptr, 0, 0, 0, s, part, coef));
-                RUN(launch_gn_finalize_fused(part, mb, tiles, Cout, h->cfg.groups, R, nullptr, nullptr, nullptr, stats, nullptr, s));
-                RUN(launch_gn_apply(raw2, dst, same ? x0 : nullptr, stats, raw(p + ".block2.norm.weight"),
-                                    raw(p + ".block2.norm.bias"), nullptr, mb, R, Cout, h->cfg.groups, s));
-            }
-            if (!same) {
-                const PackedConv* rcv = conv(p + ".res_conv.weight");
-                if (rcv)
-                    RUN(run_conv(*rcv, x0, x1, C0, C1, raw(p + ".res_conv.bias"), dst, dst, mb * F, F, Hl, Wl, Hl, Wl,
-                                 nullptr, nullptr, 0, 0, 0, s));
+                // block2's GroupNorm + SiLU: a streaming pass with the identity residual, or -- when the block has a res_conv --
+                // folded into the res_conv epilogue (block2(h) + res_conv(x) without materialising block2's activated output)
+                const PackedConv* rcv = same ? nullptr : conv(p + ".res_conv.weight");
+                const bool fuse_res = rcv && !dry() && conv_can_fuse_gn_residual(*rcv, R);
+                if (fuse_res) {
+                    RUN(launch_gn_finalize_fused(part, mb, tiles, Cout, h->cfg.groups, R, raw(p + ".block2.norm.weight"),
+                                                 raw(p + ".block2.norm.bias"), nullptr, stats, coef, s));
+                    RUN(run_conv(*rcv, x0, x1, C0, C1, raw(p + ".res_conv.bias"), nullptr, dst, mb * F, F, Hl, Wl, Hl, Wl, nullptr,
+                                 nullptr, 0, 0, 0, s, nullptr, nullptr, raw2, coef));
+                } else {
+                    RUN(launch_gn_finalize_fused(part, mb, tiles, Cout, h->cfg.groups, R, nullptr, nullptr, nullptr, stats, nullptr, s));
+                    RUN(launch_gn_apply(raw2, dst, same ? x0 : nullptr, stats, raw(p + ".block2.norm.weight"),
+                                        raw(p + ".block2.norm.bias"), nullptr, mb, R, Cout, h->cfg.groups, s));
+                    if (rcv)
+                        RUN(run_conv(*rcv, x0, x1, C0, C1, raw(p + ".res_conv.bias"), dst, dst, mb * F, F, Hl, Wl, Hl, Wl,
+                                     nullptr, nullptr, 0, 0, 0, s));
+                }
             }
             ar.release(m);
             return;
