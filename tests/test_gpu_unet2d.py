@@ -75,6 +75,30 @@ def test_micro_batching_is_exact(dev):
     assert torch.equal(y_full, y_mb)
 
 
+def test_full_size_batch_shard_invariance(dev):
+    """BASELINE.json configs[1] extent (batch 256, 16 x 128, dim 64, mults 1-2-4-8-16): a trajectory's output must not depend
+    on the batch it is evaluated in (any shard / micro-batch split): the halo-conv's partial frame tiles, the split-K rule and
+    the 16-row blocking of the time-embedding projections are all chosen from layer shapes only."""
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from oracle import unet2d as U
+    mults = (1, 2, 4, 8, 16)
+    cfg = U.Unet2DConfig(dim=64, dim_mults=mults, resnet_block_groups=1)
+    sd = U.synthetic_state_dict(cfg, seed=4)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(256, 2, 16, 128, generator=g).to(dev)
+    t = torch.randint(0, 1000, (256,), generator=g).to(dev)
+    m = Unet2D(dim=64, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=1)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    full = m(x, t)
+    assert torch.isfinite(full).all()
+    for lo, hi in ((0, 64), (64, 101), (200, 256), (255, 256)):
+        assert torch.equal(m(x[lo:hi].contiguous(), t[lo:hi].contiguous()), full[lo:hi]), (lo, hi)
+    m2 = Unet2D(dim=64, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=1, micro_batch=48)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.to(dev)(x, t), full)
+
+
 def test_unknown_parameter_and_missing_weight_fail_loudly(dev):
     import ctypes as C
     from diffphycon_amd import _lib
