@@ -59,6 +59,9 @@ def load_model(args):
         bd_updater.load_state_dict(torch.load(args.boundary_updater_model_checkpoint, map_location="cpu"))
     force_model.to(args.device).eval()
     bd_updater.to(args.device).eval()
+    # the design gradient is taken w.r.t. the surrogate INPUTS only: without this autograd also computes every weight gradient
+    for q in list(force_model.parameters()) + list(bd_updater.parameters()):
+        q.requires_grad_(False)
     diffusion = _ddpm([diffusion_joint.model, diffusion_thetas.model], args, eval_2ddpm=True, w_prob_exp=args.w_prob_exp,
                       use_guidance_in_model_predictions=args.use_guidance_in_model_predictions)
 
