@@ -84,6 +84,10 @@ struct IgemmParams {
     const float* gn_coef;
     long long gn_rows;
 };
+// f16x3 weight packers raise this device flag when a weight leaves the fp16 range after its 2^12 pre-scale (|w| > 15.99);
+// dpc_unet*_finalize reads it (a host sync, at load time only) and fails loudly instead of computing with a clamped weight.
+int* f16x3_weight_overflow_flag();          // device pointer
+int f16x3_weight_overflow_check(const char* who);   // DPC_OK, or DPC_ERR_STATE (and resets the flag)
 int igemm_npad(int N);
 int igemm_kchunks(int K);
 int launch_igemm(const IgemmParams& p, hipStream_t s);

@@ -621,9 +621,27 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     return DPC_OK;
 }
 
+static int* g_ovf_flag = nullptr;
+int* f16x3_weight_overflow_flag() {
+    if (!g_ovf_flag) {
+        if (hipMalloc(&g_ovf_flag, sizeof(int)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_ovf_flag, 0, sizeof(int));
+    }
+    return g_ovf_flag;
+}
+int f16x3_weight_overflow_check(const char* who) {
+    if (!g_ovf_flag) return DPC_OK;
+    int v = 0;
+    DPC_HIP(hipMemcpy(&v, g_ovf_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (!v) return DPC_OK;
+    (void)hipMemset(g_ovf_flag, 0, sizeof(int));
+    return fail(DPC_ERR_STATE, std::string(who) + ": a weight exceeds the f16x3 range (|w| > 15.99 after the 2^12 pre-scale); "
+                               "set DPC_CONV_MODE / DPC_IGEMM_MODE / DPC_ATTN_MODE / DPC_STEM_MODE to x6 or f32");
+}
+
 // ---- weight pre-split: reference [N][K][3][3][3] fp32 -> [27][kchunks][Npad][2 planes][16] fp16 (scaled by 2^12)
 __global__ void pack_weights_f3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int K,
-                                       int kchunks, int ntaps) {
+                                       int kchunks, int ntaps, int* __restrict__ ovf) {
     const long long total = (long long)ntaps * kchunks * Npad * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 16);
@@ -634,7 +652,11 @@ __global__ void pack_weights_f3_kernel(const float* __restrict__ w, unsigned sho
         const int tap = (int)(r / kchunks);
         const int c = kc * 16 + kk;
         float v = 0.f;
-        if (n < N && c < K) v = f3::sat16(w[((long long)n * K + c) * ntaps + tap] * f3::SW);
+        if (n < N && c < K) {
+            v = w[((long long)n * K + c) * ntaps + tap] * f3::SW;
+            if (!(fabsf(v) <= 65504.f)) atomicOr(ovf, 1);
+            v = f3::sat16(v);
+        }
         const unsigned p1 = f3::cvt_pk_f16(v, 0.f) & 0xffffu;
         const float h1 = (float)__builtin_bit_cast(f3::f16x2, p1).x;
         const unsigned p2 = f3::cvt_pk_f16(v - h1, 0.f) & 0xffffu;
@@ -649,7 +671,7 @@ int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hip
     const long long total = (long long)ntaps * kchunks * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_f3_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), N, Npad,
-                       K, kchunks, ntaps);
+                       K, kchunks, ntaps, f16x3_weight_overflow_flag());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -563,7 +563,8 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
 // ---- weight pre-split: wp6[it = tap*kchunks + kc][n][plane][kk] (bf16) from w[n*stride_n + c*stride_c + tap_off[tap]]
 struct PackTaps6 { int off[32]; };
 __global__ void pack_weights_g6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int K,
-                                       int kchunks, int ntaps, long long stride_n, long long stride_c, PackTaps6 t, int f16x3) {
+                                       int kchunks, int ntaps, long long stride_n, long long stride_c, PackTaps6 t, int f16x3,
+                                       int* __restrict__ ovf) {
     const long long total = (long long)ntaps * kchunks * Npad * 32;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 32);
@@ -576,7 +577,9 @@ __global__ void pack_weights_g6_kernel(const float* __restrict__ w, unsigned sho
         float v = 0.f;
         if (n < N && c < K) v = w[n * stride_n + c * stride_c + t.off[tap]];
         if (f16x3) {
-            v = g3::sat16(v * g3::SW);
+            v = v * g3::SW;
+            if (!(fabsf(v) <= 65504.f)) atomicOr(ovf, 1);
+            v = g3::sat16(v);
             const unsigned h1 = g3::cvt_pk_f16(v, 0.f) & 0xffffu;
             const unsigned h2 = g3::cvt_pk_f16(v - (float)__builtin_bit_cast(g3::f16x2_g, h1).x, 0.f) & 0xffffu;
             unsigned short* d3 = wp + (((long long)tap * kchunks + kc) * Npad + n) * 64 + kk;
@@ -605,7 +608,7 @@ int launch_pack_weights_g6(const float* w, void* wp6, int N, int Npad, int K, in
     const long long total = (long long)ntaps * kchunks * Npad * 32;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_g6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad,
-                       K, kchunks, ntaps, stride_n, stride_c, t, igemm_mode_default() == 2 ? 1 : 0);
+                       K, kchunks, ntaps, stride_n, stride_c, t, igemm_mode_default() == 2 ? 1 : 0, f16x3_weight_overflow_flag());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

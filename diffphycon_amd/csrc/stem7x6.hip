@@ -234,7 +234,8 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
 }
 
 // reference weight [N][C][7][7][7] fp32 -> [(df*7+dh)*4 + ks][Npad][3 planes][16] bf16, k = (dw - 2 ks) * 8 + c
-__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C, int h3) {
+__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C, int h3,
+                                    int* __restrict__ ovf) {
     const long long total = 196ll * Npad * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 16);
@@ -246,7 +247,9 @@ __global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short*
         float v = 0.f;
         if (n < N && c < C && dw < 7) v = w[(((long long)n * C + c) * 7 + df) * 49 + dh * 7 + dw];
         if (h3) {
-            v = s7::sat16(v * s7::SW);
+            v = v * s7::SW;
+            if (!(fabsf(v) <= 65504.f)) atomicOr(ovf, 1);
+            v = s7::sat16(v);
             const unsigned h1 = s7::cvt_pk_f16(v, 0.f) & 0xffffu;
             const unsigned h2 = s7::cvt_pk_f16(v - (float)__builtin_bit_cast(s7::f16x2_s, h1).x, 0.f) & 0xffffu;
             unsigned short* d3 = wp + ((long long)step * Npad + n) * 32 + kk;
@@ -270,7 +273,7 @@ int launch_pack_stem7x6(const float* w, void* wp6, int N, int Npad, int C, hipSt
     const long long total = 196ll * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_stem7x6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad, C,
-                       stem_h3() ? 1 : 0);
+                       stem_h3() ? 1 : 0, f16x3_weight_overflow_flag());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -42,7 +42,8 @@ size_t tattn3_qkv_bytes(int C) { return (size_t)4 * 3 * (C / 16) * 2048; }
 size_t tattn3_out_bytes(int C) { return (size_t)4 * (C / 32) * 2 * 2048; }
 
 // to_qkv.weight [384][C] -> [head][q|k|v][ks][plane][32 rows][2][8];  to_out.weight [C][128] -> [head][nt][s][plane][32][2][8]
-__global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int C, int is_out, int total) {
+__global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int C, int is_out, int total,
+                                   int* __restrict__ ovf) {
     using namespace t3;
     const int KS = C / 16, NTC = C / 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one value = 2 planes
@@ -63,7 +64,9 @@ __global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* 
         v = w[(long long)(nt * 32 + r) * 128 + hd * 32 + d];
         o = ((long long)((hd * NTC + nt) * 2 + s) * 2) * 512 + r * 16 + hh * 8 + i;
     }
-    v = sat16(v * SWGT);
+    v = v * SWGT;
+    if (!(fabsf(v) <= 65504.f)) atomicOr(ovf, 1);
+    v = sat16(v);
     const unsigned p1 = cvt_pk(v, 0.f) & 0xffffu;
     const unsigned p2 = cvt_pk(v - (float)__builtin_bit_cast(f16x2, p1).x, 0.f) & 0xffffu;
     dst[o] = (unsigned short)p1;
@@ -73,7 +76,7 @@ __global__ void pack_tattn3_kernel(const float* __restrict__ w, unsigned short* 
 int launch_pack_tattn3(const float* w, unsigned char* dst, int C, bool is_out, hipStream_t s) {
     const int total = is_out ? 4 * (C / 32) * 2 * 512 : 4 * 3 * (C / 16) * 512;
     hipLaunchKernelGGL(pack_tattn3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(dst),
-                       C, is_out ? 1 : 0, total);
+                       C, is_out ? 1 : 0, total, f16x3_weight_overflow_flag());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -401,6 +401,7 @@ int dpc_unet2d_finalize(dpc_unet2d_t h) {
     if (!h->have_tables) return fail(DPC_ERR_STATE, "unet2d_finalize: call dpc_unet2d_set_tables first");
     for (const auto& e : expected_names2d(h->cfg, h->dims))
         if (!h->loaded.count(e)) return fail(DPC_ERR_STATE, "unet2d_finalize: parameter not loaded: " + e);
+    if (int rc = f16x3_weight_overflow_check("unet2d_finalize")) return rc;
     h->finalized = true;
     return DPC_OK;
 }

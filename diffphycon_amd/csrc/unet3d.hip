@@ -692,6 +692,7 @@ int dpc_unet3d_finalize(dpc_unet3d_t h) {
     DPC_REQUIRE(h, "unet3d_finalize: null handle");
     for (const auto& e : expected_names(h->cfg, h->dims))
         if (!h->loaded.count(e)) return fail(DPC_ERR_STATE, "unet3d_finalize: parameter not loaded: " + e);
+    if (int rc = f16x3_weight_overflow_check("unet3d_finalize")) return rc;
     h->finalized = true;
     return DPC_OK;
 }

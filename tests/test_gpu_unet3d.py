@@ -166,6 +166,26 @@ def test_unet3d_full_size_micro_batch_invariance(dev):
     assert torch.equal(m(x[perm], t[perm]), outs[0][perm])
 
 
+def test_weight_outside_the_f16x3_range_fails_loudly(dev):
+    """The default arithmetic pre-scales weights by 2^12 into fp16: a weight above 15.99 cannot be represented and must be
+    reported at finalize time, never silently clamped."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(dim=16, dim_mults=(1, 2), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    key = next(k for k in sd if k.endswith("block1.proj.weight"))
+    sd[key] = sd[key].clone()
+    sd[key].view(-1)[7] = 40.0
+    m = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=6)
+    m.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="f16x3 range"):
+        m.to(dev)(torch.randn(1, 4, 6, 16, 16, device=dev), torch.tensor([3], device=dev))
+    # and the library stays usable afterwards (the flag is cleared when it is reported)
+    m2 = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=6)
+    m2.load_state_dict(O.synthetic_state_dict(cfg, seed=0))
+    assert torch.isfinite(m2.to(dev)(torch.randn(1, 4, 6, 16, 16, device=dev), torch.tensor([3], device=dev))).all()
+
+
 def test_unet3d_channel_view_input(dev):
     """The prior model reads x[:, :, 3:5] of the joint state in place."""
     g = load_golden("unet3d_w")
