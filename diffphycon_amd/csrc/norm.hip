@@ -218,14 +218,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
 // ---- fused-statistics path: the conv3x6 epilogue already produced per-tile channel sums (Conv3hParams::gn_part)
 // one wave per (sample, group): fold [tiles][2][C][2] fp32 partials in fp64 (fixed order), emit (mean, rstd) and the
 // per-channel coefficient table [B][C/4][5][4] = (mu, rstd*gamma, beta, scale+1, shift) for the consumer's halo load
-__global__ __launch_bounds__(256) void gn_finalize_fused_kernel(const float* __restrict__ part, float* __restrict__ stats,
+__global__ __launch_bounds__(1024) void gn_finalize_fused_kernel(const float* __restrict__ part, float* __restrict__ stats,
                                                                 float* __restrict__ coef, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
                                                                 const float* __restrict__ scale_shift, long long tiles, int C,
                                                                 int groups, long long R, int B) {
-    // one WORKGROUP per (sample, group): 256 threads stream the partials with 4 independent accumulators each (the
-    // one-wave version was latency-bound: 64 waves on the whole GPU, 256 dependent iterations per lane)
-    __shared__ double red_s[256], red_q[256];
+    // one WORKGROUP per (sample, group): 1024 threads stream the partials with 4 independent accumulators each (the kernel
+    // sits on the conv1 -> conv2 dependency chain and is pure load latency: one wave per group took 48 us, 256 threads 11 us)
+    __shared__ double red_s[1024], red_q[1024];
     const int tid = threadIdx.x;
     const int wid = blockIdx.x;
     const int b = wid / groups, g = wid % groups;
@@ -239,13 +239,13 @@ __global__ __launch_bounds__(256) void gn_finalize_fused_kernel(const float* __r
         return base + (k * C + c) * 2;
     };
     long long i = tid;
-    for (; i + 768 < total; i += 1024) {
-        const float *p0 = at(i), *p1 = at(i + 256), *p2 = at(i + 512), *p3 = at(i + 768);
+    for (; i + 3072 < total; i += 4096) {
+        const float *p0 = at(i), *p1 = at(i + 1024), *p2 = at(i + 2048), *p3 = at(i + 3072);
         const float a0 = p0[0], b0 = p0[1], a1 = p1[0], b1 = p1[1], a2 = p2[0], b2 = p2[1], a3 = p3[0], b3 = p3[1];
         s0 += (double)a0; q0 += (double)b0; s1 += (double)a1; q1 += (double)b1;
         s2 += (double)a2; q2 += (double)b2; s3 += (double)a3; q3 += (double)b3;
     }
-    for (; i < total; i += 256) {
+    for (; i < total; i += 1024) {
         const float* p0 = at(i);
         s0 += (double)p0[0];
         q0 += (double)p0[1];
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void gn_finalize_fused_kernel(const float* __r
     red_s[tid] = (s0 + s1) + (s2 + s3);
     red_q[tid] = (q0 + q1) + (q2 + q3);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (tid < o) { red_s[tid] += red_s[tid + o]; red_q[tid] += red_q[tid + o]; }
         __syncthreads();
     }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void gn_finalize_fused_kernel(const float* __r
         stats[2 * wid + 1] = rstd;
     }
     if (coef) {
-        for (int c = tid; c < cpg; c += 256) {
+        for (int c = tid; c < cpg; c += 1024) {
             const int ch = g * cpg + c;
             float* dst = coef + ((long long)b * (C >> 2) + (ch >> 2)) * 20 + (ch & 3);
             dst[0] = mu;
@@ -285,7 +285,7 @@ int launch_gn_finalize_fused(const float* part, int B, long long tiles, int C, i
     DPC_REQUIRE(groups >= 1 && C % groups == 0 && C % 4 == 0, "gn_finalize_fused: groups must divide C, C % 4 == 0");
     if (B == 0) return DPC_OK;
     ProfScope prof(PROF_GN, 0, 4.0 * (double)B * tiles * 2 * C * 2, s);
-    hipLaunchKernelGGL(gn_finalize_fused_kernel, dim3(B * groups), dim3(256), 0, s, part, stats, coef, gamma, beta,
+    hipLaunchKernelGGL(gn_finalize_fused_kernel, dim3(B * groups), dim3(1024), 0, s, part, stats, coef, gamma, beta,
                        scale_shift, tiles, C, groups, R, B);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
