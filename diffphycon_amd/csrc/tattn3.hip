@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
     constexpr int C = G::C, KS = G::KS, NTC = G::NTC, NH = G::NH, HEAD_QKV = G::HEAD_QKV, HEAD_OUT = G::HEAD_OUT;
     constexpr int QKV_RES = G::QKV_RES, OUT_RES = G::OUT_RES, OFF_COS = G::OFF_COS, OFF_SIN = G::OFF_SIN, OFF_BIAS = G::OFF_BIAS;
     constexpr int HD0 = PASS == 2 ? 2 : 0;             // first resident head
-    constexpr bool PREFETCH = C == 64;                 // C = 128: the row registers are needed for xs / y
+    constexpr bool PREFETCH = C == 64 && FULL;         // C = 128 and the masked (F < 32) form: the row registers are needed elsewhere
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int loff = l31 * 32 + hh * 16;
