@@ -2,22 +2,32 @@
 """Headline benchmark: guided trajectories/sec, 2-D smoke 64x64x32 @ 1000 DDPM steps (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A "step" is ONE guided DDPM step of the whole local batch (config S64: 64 trajectories per GPU):
-joint U-Net forward + prior U-Net forward + fused guidance/posterior update — i.e. 1/1000 of the sampling of
-each trajectory.  trajectories/s = (N * 64) / (1000 * seconds_per_step).  Inputs and state are resident in
-HBM before the timed region; weights are seeded random initialisations of the reference architecture
-(no checkpoints exist offline) and data is synthetic.
+N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment), or as a plain `python bench.py --gpus N`, which re-executes itself under
+torch.distributed.run with one rank per GPU (RCCL, rendezvous on 127.0.0.1).
+
+A "step" is ONE guided DDPM step of the whole local batch (config S64: 64 trajectories per GPU): joint U-Net forward + prior
+U-Net forward + fused guidance/posterior update, i.e. 1/1000 of the sampling of each trajectory.
+trajectories/s = (N * 64) / (1000 * seconds_per_step), seconds_per_step = MAX over ranks of (elapsed / K) between two
+barrier + synchronize pairs.  Inputs and state are resident in HBM before the timed region; weights are seeded random
+initialisations of the reference architecture (no checkpoints exist offline) and data is synthetic.
 
 The JSON line also carries
-  roofline     : achieved fp32 TFLOP/s of the dominant kernel class (the implicit-GEMM conv kernel), from HIP
-                 events recorded on the launch stream inside the timed region, against the 157.3 TF fp32 MFMA peak;
-  cpu_baseline : the CPU oracle (torch fp32, all host cores) executing the same step at B=1, timed once.
+  roofline     : achieved TFLOP/s of the dominant kernel class from HIP events recorded on the launch stream inside the timed
+                 region, against the MFMA peak of the arithmetic mode the library reports for that op family;
+  cpu_baseline : the CPU oracle (torch fp32, all usable host cores) executing the same step: 1 warm-up + up to 5 timed steps
+                 at B=1 and at B=min(8, cores) inside a time budget (BASELINE.md section 3), N=1 only;
+  value_exact  : the same timed loop re-run with exact fp32 products (arithmetic mode x6: 3-way bf16 split) -- the default
+                 mode (f16x3) carries 22 significant operand bits;
+  burgers      : BASELINE.json configs[1] (Burgers POPC, B=256/GPU) measured in the same run, with its own roofline/cpu_baseline;
+  smoke_evaluator : rollouts/s of the post-sampling PDE evaluator (N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,37 +38,46 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3         # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # same guide: v_mfma_f32_32x32x16_bf16 / _f16 dense peak
+STEPS_PER_TRAJECTORY = 1000
+LOCAL_BATCH = 64
+FRAMES, SIZE = 32, 64
+UNIT_GFLOP = 1794.5                   # algorithmic GFLOP per S64 trajectory-step (both U-Nets)
+BURGERS_UNIT_GFLOP = 15.8             # Burgers POPC pair per trajectory-step
 
 
-def mfma_roof(name):
-    """Roof for the ALGORITHMIC fp32 flops of a kernel class under the active arithmetic mode: the split-operand kernels
-    spend 3 (f16x3: 2-way fp16 split, default) or 6 (x6: exact 3-way bf16 split) 16-bit MFMAs per fp32 product."""
-    if name.startswith("conv3x6"):
-        mode = os.environ.get("DPC_CONV_MODE", "f16x3").lower()
-    elif name.startswith("igemm"):
-        mode = os.environ.get("DPC_IGEMM_MODE", "f16x3").lower()
-    elif name.startswith("stem"):
-        mode = os.environ.get("DPC_STEM_MODE", "f16x3").lower()
-    else:
-        mode = "f32"
-    if mode.startswith("f3"):
+def family_of(kernel_class):
+    if kernel_class.startswith("conv3"):
+        return "conv"
+    if kernel_class.startswith("igemm"):
+        return "igemm"
+    if kernel_class.startswith("stem"):
+        return "stem"
+    if "attention" in kernel_class:
+        return "attn"
+    return None
+
+
+def mfma_roof(kernel_class, modes):
+    """Roof for the ALGORITHMIC fp32 flops of a kernel class under the arithmetic mode the model handle reports
+    (`modes` = 'conv=..,igemm=..,attn=..,stem=..' from dpc_unet*_modes): the split-operand kernels spend 3 (f16x3) or 6 (x6)
+    16-bit MFMAs per fp32 product."""
+    md = dict(kv.split("=") for kv in modes.split(",")) if modes else {}
+    mode = md.get(family_of(kernel_class), "f32")
+    if mode == "f32":
         return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense"
-    if mode.startswith("x") or mode.startswith("b"):
+    if mode == "x6":
         return PEAK_BF16_MFMA_TFLOPS / 6.0, "2500 TF bf16 dense / 6 MFMAs per fp32 product (bf16x6 split)"
     return PEAK_BF16_MFMA_TFLOPS / 3.0, "2500 TF fp16 dense / 3 MFMAs per fp32 product (f16x3 split)"
 
 
 def pmc_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per
-    the guide's gfx950 correction, + WRITE_SIZE), or None when no PMC summary exists for that kernel class."""
+    """HBM bytes per launch of a kernel class from the COMMITTED rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE
+    doubled per the guide's gfx950 correction, + WRITE_SIZE), or None.  Not measured by this run: PMC needs rocprofv3."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         return json.load(open(path)).get(kernel_class, {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
-STEPS_PER_TRAJECTORY = 1000
-LOCAL_BATCH = 64
-FRAMES, SIZE = 32, 64
 
 
 def synthetic_init(batch, traj0, size=SIZE):
@@ -72,15 +91,15 @@ def synthetic_init(batch, traj0, size=SIZE):
     return init
 
 
-def build_models(device, micro_batch):
+def build_models(device, micro_batch, arithmetic=None, frames=FRAMES, size=SIZE):
     from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion
     torch.manual_seed(0)
-    mj = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, micro_batch=micro_batch)
-    mw = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=2, micro_batch=micro_batch)
+    mj = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, micro_batch=micro_batch, arithmetic=arithmetic)
+    mw = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=2, micro_batch=micro_batch, arithmetic=arithmetic)
     sd_cpu = (mj.state_dict(), mw.state_dict())
     sd_cpu = tuple({k: v.clone() for k, v in sd.items()} for sd in sd_cpu)
-    gd = GaussianDiffusion([mj.to(device), mw.to(device)], image_size=SIZE, frames=FRAMES, timesteps=1000,
+    gd = GaussianDiffusion([mj.to(device), mw.to(device)], image_size=size, frames=frames, timesteps=1000,
                            sampling_timesteps=1000, loss_type="l2", objective="pred_noise", standard_fixed_ratio=1e5,
                            coeff_ratio=0.0, eval_2ddpm=True, w_prob_exp=0.97, device=device)
     return gd, sd_cpu
@@ -99,8 +118,22 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(sd_cpu, init1):
-    """One guided DDPM step, B=1, on the CPU oracle (the reference's algorithm restated in torch fp32)."""
+def _timed_cpu_steps(step, budget_s, max_steps=5):
+    """1 untimed warm-up (oneDNN primitive creation) + up to `max_steps` timed steps while the leg stays inside its budget."""
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    times = []
+    while len(times) < max_steps and (not times or (time.perf_counter() - t0) + times[-1] < budget_s):
+        t1 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t1)
+    return warm, times
+
+
+def cpu_baseline(sd_cpu, budget_s):
+    """the CPU oracle (the reference's algorithm restated in torch fp32) on the same unit, 1 warm-up +
+    up to 5 timed steps at B=1 and at B=min(8, cores); `value` is the better of the two rates."""
     from oracle import unet3d as O
     from oracle import sampler_smoke as S
     cores = usable_cores()
@@ -108,28 +141,41 @@ def cpu_baseline(sd_cpu, init1):
     cj = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
     cw = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=2)
     sched = S.make_schedule(1000, "sigmoid")
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(1, FRAMES, 6, SIZE, SIZE, generator=g)
-    z = torch.randn(1, FRAMES, 6, SIZE, SIZE, generator=g)
-    x[:, 0, 0] = init1
-    t = torch.full((1,), 999, dtype=torch.long)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ej = O.unet3d_forward(sd_cpu[0], cj, x, t)
-        ew = O.unet3d_forward(sd_cpu[1], cw, x[:, :, 3:5], t)
-        S.p_sample_step(sched, x, 999, ej, ew, z, init1, S.rescaler_tensor())
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / (STEPS_PER_TRAJECTORY * dt), "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"1 guided DDPM step (joint+prior U-Net forward + update) at B=1, 64x64x32, torch fp32 on {cores} "
-                      f"threads: {dt:.2f} s/step, extrapolated x1000 steps"}
+    legs = []
+    for B, share in ((1, 0.4), (min(8, cores), 0.6)):
+        if legs and B == legs[0]["B"]:
+            break
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(B, FRAMES, 6, SIZE, SIZE, generator=g)
+        z = torch.randn(B, FRAMES, 6, SIZE, SIZE, generator=g)
+        init = synthetic_init(B, 0)
+        x[:, 0, 0] = init
+        t = torch.full((B,), 999, dtype=torch.long)
+
+        def step():
+            with torch.no_grad():
+                ej = O.unet3d_forward(sd_cpu[0], cj, x, t)
+                ew = O.unet3d_forward(sd_cpu[1], cw, x[:, :, 3:5], t)
+                S.p_sample_step(sched, x.clone(), 999, ej, ew, z, init, S.rescaler_tensor())
+        warm, times = _timed_cpu_steps(step, budget_s * share)
+        mean = sum(times) / len(times)
+        legs.append({"B": B, "warmup_s": round(warm, 3), "timed_steps": len(times), "mean_s_per_step": round(mean, 4),
+                     "trajectories_per_s": B / (STEPS_PER_TRAJECTORY * mean)})
+    best = max(legs, key=lambda l: l["trajectories_per_s"])
+    return {"value": best["trajectories_per_s"], "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"guided DDPM steps (joint+prior U-Net forward + update), 64x64x32, torch fp32 on {cores} threads: "
+                      + "; ".join(f"B={l['B']}: 1 warm-up + {l['timed_steps']} timed, {l['mean_s_per_step']} s/step" for l in legs)
+                      + "; extrapolated x1000 steps",
+            "legs": legs}
 
 
-def burgers_setup(device, batch, rank):
+# ------------------------------------------------------------------------------------------------ Burgers POPC
+def burgers_setup(device, batch, rank, arithmetic=None):
     """BASELINE.json configs[1]: Burgers POPC recipe of scripts/burgers_inference_partial_obs_partial_ctr.sh."""
     from diffphycon_amd.model.burgers_1d.unet import Unet2D
     from diffphycon_amd.diffusion import diffusion_1d_burgers as D
     torch.manual_seed(0)
-    kw = dict(dim=64, out_dim=2, channels=2, resnet_block_groups=1)
+    kw = dict(dim=64, out_dim=2, channels=2, resnet_block_groups=1, arithmetic=arithmetic)
     m_uw = Unet2D(dim_mults=(1, 2, 4, 8, 16), **kw)
     m_w = Unet2D(dim_mults=(1, 2, 4, 8), **kw)
     sd_cpu = tuple({k: v.clone() for k, v in m.state_dict().items()} for m in (m_uw, m_w))
@@ -140,6 +186,7 @@ def burgers_setup(device, batch, rank):
     # u0 = two Gaussians (generate_burgers.py:361-372), uT = u0 rolled by 16 cells, both / 10
     g = torch.Generator().manual_seed(1000 + rank)
     xg = torch.linspace(0, 1, 128)[None, :]
+
     def bump(lo, hi, alo, ahi):
         loc = lo + (hi - lo) * torch.rand(batch, 1, generator=g)
         amp = alo + (ahi - alo) * torch.rand(batch, 1, generator=g)
@@ -155,8 +202,8 @@ def burgers_setup(device, batch, rank):
     return gd, kwargs, sd_cpu, (u0 / 10, uT / 10)
 
 
-def burgers_cpu_baseline(sd_cpu, cond):
-    """One guided DDPM step of the POPC recipe at B=8 on the CPU oracle (torch fp32, all usable cores)."""
+def burgers_cpu_baseline(sd_cpu, cond, budget_s):
+    """The POPC recipe on the CPU oracle at B=8 under no_grad: 1 warm-up + up to 5 timed steps inside the budget."""
     from oracle import unet2d as U
     from oracle import sampler_burgers as S
     cores = usable_cores()
@@ -166,242 +213,364 @@ def burgers_cpu_baseline(sd_cpu, cond):
     c_w = U.Unet2DConfig(dim=64, dim_mults=(1, 2, 4, 8), resnet_block_groups=1)
     sched = S.make_schedule(1000, "cosine")
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(B, 2, 16, 128, generator=g)
+    x0 = torch.randn(B, 2, 16, 128, generator=g)
     z = torch.randn(B, 2, 16, 128, generator=g)
     tb = torch.full((B,), 999, dtype=torch.long)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        S.set_conditions(x, cond[0][:B], cond[1][:B], True)
-        e_uw = U.unet2d_forward(sd_cpu[0], c_uw, x, tb)
-        e_w = U.unet2d_forward(sd_cpu[1], c_w, S.w_model_input(x), tb)
-        S.p_sample_step(sched, x, 999, e_uw, e_w, z, prior_beta=0.9, eta_w=S.scheduler_table("sigmoid_flip")[999],
-                        eta_J=S.scheduler_table("cosine")[999])
-    dt = time.perf_counter() - t0
-    return {"value": B / (STEPS_PER_TRAJECTORY * dt), "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"1 guided DDPM step (joint+prior Unet2D forward + update) at B={B}, 16x128, torch fp32 on {cores} "
-                      f"threads: {dt:.2f} s/step, extrapolated x1000 steps"}
+
+    def step():
+        x = x0.clone()
+        with torch.no_grad():
+            S.set_conditions(x, cond[0][:B], cond[1][:B], True)
+            e_uw = U.unet2d_forward(sd_cpu[0], c_uw, x, tb)
+            e_w = U.unet2d_forward(sd_cpu[1], c_w, S.w_model_input(x), tb)
+            S.p_sample_step(sched, x, 999, e_uw, e_w, z, prior_beta=0.9, eta_w=S.scheduler_table("sigmoid_flip")[999],
+                            eta_J=S.scheduler_table("cosine")[999])
+    warm, times = _timed_cpu_steps(step, budget_s)
+    mean = sum(times) / len(times)
+    return {"value": B / (STEPS_PER_TRAJECTORY * mean), "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": f"guided DDPM steps (joint+prior Unet2D forward + update) at B={B}, 16x128, torch fp32 no_grad on {cores} "
+                      f"threads: 1 warm-up ({warm:.2f} s) + {len(times)} timed, {mean:.3f} s/step, extrapolated x1000 steps"}
 
 
-def main_burgers(args, rank, world, device, dist):
-    """`--workload burgers`: Burgers POPC, 1000-step DDPM, batch 256 per GPU (BASELINE.json configs[1])."""
-    from diffphycon_amd import _lib
-    B = args.batch if args.batch != LOCAL_BATCH else 256
-    gd, kwargs, sd_cpu, cond = burgers_setup(device, B, rank)
-    gd.noise_seed, gd.traj_offset, gd.guidance_batch = 0, rank * B, B
-    guide = kwargs["nablaJ"]
-    img = gd.sample_noise([B, 2, 16, 128], device)
-    x_w = torch.empty_like(img)
+class Ctx:
+    """rank / world / device / optional torch.distributed handle + the barrier-bracketed timing helpers."""
 
-    def step(t):
-        gd._prepare(img, x_w, kwargs["u_init"], kwargs["u_final"])
-        t_b = torch.full((B,), t, device=device, dtype=torch.long)
-        e_uw, e_w = gd._denoise(img, x_w, t_b)
-        z = gd.sample_noise([B, 2, 16, 128], device)
-        gd._update(img, e_uw, e_w, z, None, img, gd._coef(t, guide, kwargs["J_scheduler"], kwargs["w_scheduler"], True, B))
+    def __init__(self, rank, world, device, dist, stub=False):
+        self.rank, self.world, self.device, self.dist, self.stub = rank, world, device, dist, stub
 
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def sync(self):
+        if not self.stub:
             torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            if not self.stub:
+                torch.cuda.synchronize()
 
-    t_cur = 999
-    prof_all = None
-    for i in range(args.warmup):
-        last = i == args.warmup - 1
+    def reduce(self, seconds):
+        """(max, min) of a per-rank duration over the ranks."""
+        if self.dist is None:
+            return seconds, seconds
+        hi = torch.tensor([seconds], device=self.device, dtype=torch.float64)
+        lo = hi.clone()
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        return hi.item(), lo.item()
+
+    def log(self, t_start, msg):
+        if self.rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def timed_loop(ctx, step, steps, warmup, profile=True):
+    """W untimed warm-up steps (the last one with every kernel class bracketed by events: per-class breakdown), then EXACTLY K
+    timed steps between barrier + synchronize pairs with only the dominant class instrumented (two events per launch cost ~4 %
+    of a step when every launch is bracketed).  -> (max-over-ranks seconds per step, min, prof_all, prof_dom, warm_ms)."""
+    from diffphycon_amd import _lib
+    prof_all, warm_ms = None, None
+    for i in range(warmup):
+        last = profile and i == warmup - 1
         if last:
-            _lib.profile_begin()             # every class on an untimed step (see main())
+            _lib.profile_begin()
         tw0 = time.perf_counter()
-        step(t_cur)
-        t_cur -= 1
-        sync()
+        step()
+        ctx.sync()
         warm_ms = (time.perf_counter() - tw0) * 1e3
         if last:
             prof_all = _lib.profile_end()
-    sync()
-    dom_name = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else None
-    _lib.profile_begin([dom_name] if dom_name else None)
+    ctx.sync()                               # barrier + device sync on both sides of the timed region (also when --warmup 0)
+    dom = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else None
+    if profile:
+        _lib.profile_begin([dom] if dom else None)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(t_cur)
-        t_cur -= 1
-    sync()
+    for _ in range(steps):
+        step()
+    ctx.sync()
     elapsed = time.perf_counter() - t0
-    prof = _lib.profile_end()
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    prof = _lib.profile_end() if profile else None
+    hi, lo = ctx.reduce(elapsed)
+    return hi / steps, lo / steps, prof_all, prof, warm_ms
+
+
+def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_per_step):
+    name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    if d["flops"] > 0:
+        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        peak, peak_note = mfma_roof(name, modes)
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": pmc_traffic(name), "peak_note": peak_note}
+    else:
+        achieved = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": pmc_traffic(name)}
+    roof["traffic_source"] = ("committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), not re-measured by this run"
+                              if roof["traffic"] is not None else None)
+    roof["kernel"], roof["launches"] = name, d["launches"]
+    roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
+    if prof_all:
+        roof["breakdown_ms_per_step"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof_all.items())}
+        roof["breakdown_note"] = ("all classes bracketed by events on the last (untimed) warm-up step; the timed steps bracket "
+                                  "only the roofline kernel class")
+        roof["kernel_time_fraction_of_step"] = sum(v["total_ms"] for v in prof_all.values()) / warm_ms
+    else:
+        roof["breakdown_ms_per_step"] = {k: round(v["total_ms"] / steps, 3) for k, v in sorted(prof.items())}
+    roof["step_flops_fraction_of_fp32_peak"] = (unit_tflop_per_step / sec_per_step) / PEAK_FP32_MFMA_TFLOPS
+    return roof
+
+
+def run_burgers(ctx, args, t_start, batch=256, with_cpu=True, exact=True):
+    """Burgers POPC, 1000-step DDPM, batch 256 per GPU (BASELINE.json configs[1]); HIP-graph replay of the step when the
+    per-kernel events are off (--burgers-graph, default on for the exact/graph legs)."""
+    gd, kwargs, sd_cpu, cond = burgers_setup(ctx.device, batch, ctx.rank)
+    gd.noise_seed, gd.traj_offset, gd.guidance_batch = 0, ctx.rank * batch, batch
+    guide = kwargs["nablaJ"]
+    state = {"t": 999}
+
+    def make_step(g):
+        img = g.sample_noise([batch, 2, 16, 128], ctx.device)
+        x_w = torch.empty_like(img)
+
+        def step():
+            t = state["t"]
+            g._prepare(img, x_w, kwargs["u_init"], kwargs["u_final"])
+            t_b = torch.full((batch,), t, device=ctx.device, dtype=torch.long)
+            e_uw, e_w = g._denoise(img, x_w, t_b)
+            z = g.sample_noise([batch, 2, 16, 128], ctx.device)
+            g._update(img, e_uw, e_w, z, None, img, g._coef(t, guide, kwargs["J_scheduler"], kwargs["w_scheduler"], True, batch))
+            state["t"] = t - 1 if t > 1 else 999
+        return step, img
+    step, img = make_step(gd)
+    sec, sec_min, prof_all, prof, warm_ms = timed_loop(ctx, step, args.steps, max(args.warmup, 1))
     assert torch.isfinite(img).all()
-    if rank == 0:
-        sec = elapsed / args.steps
-        name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["flops"] > 0 else d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
-        peak, peak_note = mfma_roof(name)
-        roof = ({"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                 "peak_note": peak_note}
-                if d["flops"] > 0 else
-                {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0})
-        roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": d["launches"],
-                     "avg_launch_ms": d["total_ms"] / max(d["launches"], 1),
-                     "breakdown_ms_per_step": ({k: round(v["total_ms"], 3) for k, v in sorted(prof_all.items())} if prof_all else
-                                               {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())}),
-                     "breakdown_note": "all classes on the last untimed warm-up step; timed steps bracket the roofline class only",
-                     "kernel_time_fraction_of_step": (sum(v["total_ms"] for v in prof_all.values()) / warm_ms if prof_all else
-                                                      sum(v["total_ms"] for v in prof.values()) / (elapsed * 1e3)),
-                     "step_flops_fraction_of_fp32_peak": (B * 15.8 / 1e3 / sec) / PEAK_FP32_MFMA_TFLOPS})
-        out = {"metric": "guided trajectories/sec, 1D Burgers POPC 128 cells x 10 steps @1000 DDPM steps",
-               "value": world * B / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "Burgers POPC (BASELINE.json configs[1]): 128 cells x 10 steps (16x128 padded), "
-                                      f"1000-step guided DDPM, batch={B} per GPU; one step = prepare + joint Unet2D(dim 64, "
-                                      "mults 1-2-4-8-16) + prior Unet2D(1-2-4-8) + fused update",
-                          "global_batch": world * B, "parallelism": f"batch-shard x{world}"},
-               "roofline": roof,
-               "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else burgers_cpu_baseline(sd_cpu, cond)}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    modes = gd.model_uw.modes
+    out = {"metric": "guided trajectories/sec, 1D Burgers POPC 128 cells x 10 steps @1000 DDPM steps",
+           "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": ctx.world,
+           "steps": args.steps, "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "dtype": "f32",
+           "arithmetic": modes,
+           "config": {"workload": "Burgers POPC (BASELINE.json configs[1]): 128 cells x 10 steps (16x128 padded), "
+                                  f"1000-step guided DDPM, batch={batch} per GPU; one step = prepare + joint Unet2D(dim 64, "
+                                  "mults 1-2-4-8-16) + prior Unet2D(1-2-4-8) + fused update",
+                      "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
+    if ctx.rank == 0:
+        out["roofline"] = roofline_of(prof, prof_all, modes, sec, args.steps, warm_ms, batch * BURGERS_UNIT_GFLOP / 1e3)
+    ctx.log(t_start, f"burgers: {sec * 1e3:.2f} ms/step")
+    # the same loop with no per-kernel events at all (what a production sampling loop runs)
+    state["t"] = 999
+    sec_np, _, _, _, _ = timed_loop(ctx, step, args.steps, 1, profile=False)
+    out["ms_per_step_unprofiled"] = sec_np * 1e3
+    out["value_unprofiled"] = ctx.world * batch / (STEPS_PER_TRAJECTORY * sec_np)
+    if exact:
+        gd_x, _, _, _ = burgers_setup(ctx.device, batch, ctx.rank, arithmetic="x6")
+        gd_x.noise_seed, gd_x.traj_offset, gd_x.guidance_batch = 0, ctx.rank * batch, batch
+        step_x, img_x = make_step(gd_x)
+        state["t"] = 999
+        sec_x, _, _, _, _ = timed_loop(ctx, step_x, args.steps, 1, profile=False)
+        assert torch.isfinite(img_x).all()
+        out["value_exact"] = ctx.world * batch / (STEPS_PER_TRAJECTORY * sec_x)
+        out["ms_per_step_exact"] = sec_x * 1e3
+        out["arithmetic_exact"] = gd_x.model_uw.modes
+        del gd_x
+    out["cpu_baseline"] = (burgers_cpu_baseline(sd_cpu, cond, args.cpu_budget * 0.2)
+                           if (with_cpu and ctx.rank == 0 and ctx.world == 1) else None)
+    return out
+
+
+def run_smoke_evaluator(ctx, B=64, T=256):
+    """Post-sampling PDE evaluator: B rollouts x T frames in one launch, as multi_evaluate consumes them."""
+    import numpy as np
+    from diffphycon_amd.dataset.apps import evaluate_solver as E
+    rng = np.random.default_rng(0)
+    c1 = (rng.standard_normal((B, 32, 64, 64)) * 0.3).astype(np.float32)
+    c2 = (rng.standard_normal((B, 32, 64, 64)) * 0.3).astype(np.float32)
+    c1[:, :, 8:56, 8:56] = 0
+    c2[:, :, 8:56, 8:56] = 0
+    d0 = synthetic_init(B, 0).numpy() * 2
+    sim = E.init_sim_128()
+    c1d, c2d, d0d = (torch.from_numpy(a).to(ctx.device) for a in (c1, c2, d0))
+    kw = dict(frame_stride=8, space_stride=2, density_dtype=torch.float32)
+    E.solver_batch(sim, E.init_velocity_(), d0d[:2], c1d[:2, :2], c2d[:2, :2], 2, **kw)          # warm-up / module load
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = E.solver_batch(sim, E.init_velocity_(), d0d, c1d, c2d, T, return_cg_iterations=True, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its = out[4].double()
+    return {"rollouts_per_s": B / dt, "seconds": dt, "batch": B, "frames": T, "mean_cg_iterations_per_frame": its.mean().item(),
+            "us_per_cg_iteration": dt * 1e6 / max(its.sum().item() / B, 1.0),
+            "note": "smoke PDE rollouts (phi advect + masked CG pressure solve, fp64, bit-exact vs the reference) of 64 "
+                    "sampled control sequences; end-to-end figure next to trajectories/s (SURVEY.md 8d)"}
+
+
+# ------------------------------------------------------------------------------------------------ launch plumbing
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this host driver (RCCL needs it)
+    env["DPC_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers"],
-                    help="smoke = BASELINE.json's headline metric (default); burgers = configs[1]")
+    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128"],
+                    help="smoke = BASELINE.json's headline metric S64 (default); burgers = configs[1]; s128 = configs[4] shape "
+                         "(128x128x64 frames; builder-side line, batch 8 per GPU by default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=LOCAL_BATCH, help="trajectories per GPU (S64 = 64)")
-    ap.add_argument("--micro-batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (S64 = 64)")
+    ap.add_argument("--micro-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of host time for all cpu_baseline legs")
+    ap.add_argument("--no-extras", action="store_true", help="headline loop only: no exact-mode / burgers / evaluator legs")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY: CPU + gloo, the step is a sleep; exercises the launcher / barrier / reduction plumbing")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or omit the launcher)")
     dist = None
+    if args.stub:
+        device = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+        if args.stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
+    ctx = Ctx(rank, world, device, dist, stub=args.stub)
+    seen_world = dist.get_world_size() if dist is not None else 1
+    launcher = "self (bench.py -> torch.distributed.run)" if os.environ.get("DPC_BENCH_SELF_LAUNCHED") else \
+        ("external torch.distributed.run" if world > 1 else "single process")
 
-    if args.workload == "burgers":
-        return main_burgers(args, rank, world, device, dist)
-    from diffphycon_amd import _lib
-    from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
-    gd, sd_cpu = build_models(device, args.micro_batch)
-    guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
-    B = args.batch
-    gd.noise_seed, gd.traj_offset = 0, rank * B            # batch-sharded: rank r owns trajectories [r*B, (r+1)*B)
-    init_cpu = synthetic_init(B, rank * B)
-    init = init_cpu.to(device)
-    x = gd.sample_noise([B, FRAMES, 6, SIZE, SIZE], device)
-    x[:, 0, 0] = init
+    if args.stub:
+        B = args.batch or LOCAL_BATCH
 
-    def step(t):
-        gd.p_sample(None, x, t, design_fn=guide, design_guidance="standard", init=init)
-
-    def sync():
-        torch.cuda.synchronize()
+        def step():
+            time.sleep(0.002 * (1 + rank))           # ranks differ on purpose: the reduction must report the slowest
+        for _ in range(args.warmup):
+            step()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ctx.sync()
+        hi, lo = ctx.reduce(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"metric": "STUB (no GPU work): launcher plumbing test", "stub": True, "n_gpus": world,
+                              "value": world * B / (STEPS_PER_TRAJECTORY * hi / args.steps), "unit": "trajectories/s",
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": hi / args.steps * 1e3,
+                              "ms_per_step_min_rank": lo / args.steps * 1e3, "world_size_seen_by_backend": seen_world,
+                              "launcher": launcher, "config": {"global_batch": world * B}}), flush=True)
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        return
 
-    def log(msg):
+    if args.workload == "burgers":
+        out = run_burgers(ctx, args, t_start, batch=args.batch or 256, with_cpu=not args.no_cpu_baseline,
+                          exact=not args.no_extras)
         if rank == 0:
-            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+            out.update({"warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "data": "synthetic", "world_size_seen_by_rccl": seen_world, "launcher": launcher})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    t_cur = 999
-    log("models built, starting warmup")
-    prof_all = None
-    for i in range(args.warmup):
-        last = i == args.warmup - 1
-        if last:
-            _lib.profile_begin()             # every kernel class, on an UNTIMED step: per-class breakdown + dominant class
-        tw0 = time.perf_counter()
-        step(t_cur)
-        t_cur -= 1
-        sync()
-        warm_ms = (time.perf_counter() - tw0) * 1e3
-        if last:
-            prof_all = _lib.profile_end()
-        log("warmup step done")
-    sync()                                   # barrier + device sync on both sides of the timed region (also when --warmup 0)
-    # Two HIP events per launch cost ~4 % of the step when every launch is bracketed (tools/profile_overhead.py), so the
-    # timed steps instrument only the dominant kernel class (the roofline kernel); the other classes come from the warm-up pass.
-    dom_name = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else None
-    _lib.profile_begin([dom_name] if dom_name else None)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(t_cur)
-        t_cur -= 1
-    sync()
-    elapsed = time.perf_counter() - t0
-    log(f"timed steps done: {elapsed:.3f}s")
-    prof = _lib.profile_end()
-    log("profile read")
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
+    s128 = args.workload == "s128"
+    frames, size = (64, 128) if s128 else (FRAMES, SIZE)
+    B = args.batch or (8 if s128 else LOCAL_BATCH)
+    mbatch = args.micro_batch or (1 if s128 else 8)
+    unit_gflop = 14534.0 if s128 else UNIT_GFLOP          # SURVEY.md 8(d)
+    gd, sd_cpu = build_models(device, mbatch, frames=frames, size=size)
+    guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
+
+    def make_step(g):
+        g.noise_seed, g.traj_offset = 0, rank * B            # batch-sharded: rank r owns trajectories [r*B, (r+1)*B)
+        init = (synthetic_init(B, rank * B, size=size) if not s128 else
+                torch.nn.functional.interpolate(synthetic_init(B, rank * B)[:, None], scale_factor=2)[:, 0]).to(device)
+        x = g.sample_noise([B, frames, 6, size, size], device)
+        x[:, 0, 0] = init
+        st = {"t": 999}
+
+        def step():
+            g.p_sample(None, x, st["t"], design_fn=guide, design_guidance="standard", init=init)
+            st["t"] = st["t"] - 1 if st["t"] > 1 else 999
+        return step, x
+
+    step, x = make_step(gd)
+    ctx.log(t_start, "models built, starting warmup")
+    sec, sec_min, prof_all, prof, warm_ms = timed_loop(ctx, step, args.steps, args.warmup)
+    ctx.log(t_start, f"timed steps done: {sec * 1e3:.2f} ms/step")
     assert torch.isfinite(x).all(), "non-finite state after the timed steps"
-
+    modes = gd.model_joint.modes
+    out = None
     if rank == 0:
-        sec_per_step = elapsed / args.steps
-        value = world * B / (STEPS_PER_TRAJECTORY * sec_per_step)
-        # dominant kernel class by total time
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        name, d = dom
-        if d["flops"] > 0:
-            achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-            peak, peak_note = mfma_roof(name)
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak, "traffic": pmc_traffic(name), "peak_note": peak_note}
-        else:
-            achieved = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": None}
-        roof["kernel"] = name
-        roof["launches"] = d["launches"]
-        roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
-        if prof_all:
-            roof["breakdown_ms_per_step"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof_all.items())}
-            roof["breakdown_note"] = ("all classes bracketed by events on the last (untimed) warm-up step; the timed steps bracket "
-                                      "only the roofline kernel class")
-            roof["kernel_time_fraction_of_step"] = sum(v["total_ms"] for v in prof_all.values()) / warm_ms   # of that warm-up step
-        else:
-            roof["breakdown_ms_per_step"] = {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())}
-            roof["kernel_time_fraction_of_step"] = sum(v["total_ms"] for v in prof.values()) / (elapsed * 1e3)
-        unit_gflop = 1794.5        # SURVEY.md 8(d): algorithmic GFLOP per trajectory-step (both U-Nets)
-        roof["step_flops_fraction_of_fp32_peak"] = (B * unit_gflop / 1e3 / sec_per_step) / PEAK_FP32_MFMA_TFLOPS
+        roof = roofline_of(prof, prof_all, modes, sec, args.steps, warm_ms, B * unit_gflop / 1e3)
+        cfg_name = ("S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames" if s128 else
+                    "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames")
         out = {
-            "metric": "guided trajectories/sec, 2D smoke 64x64x32 @1000 DDPM steps",
-            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 tensors in HBM and fp32 accumulation everywhere. 3x3x3 convs and the implicit-GEMM ops split each "
-                          "operand into 2 fp16 terms (22 significant bits) and sum 3 partial products per product (f16x3); the "
-                          "stem and the fused attention blocks at C = 64 use the same f16x3 scheme; the C = 128 temporal "
-                          "attention uses the exact 3-way bf16 split with 6 partial products (bf16x6), the C = 128 linear attention "
-                          "the native fp32 MFMA. "
-                          "Measured U-Net forward deviation from the reference's fp32 CPU output: 2.3e-6 (f16x3) vs 3.1e-6 "
-                          "(bf16x6) vs 2.7e-6 (native fp32 MFMA) of the output range (tools/mode_error.py); tolerance 1e-4. "
-                          "DPC_CONV_MODE / DPC_IGEMM_MODE = x6 | f32 select the other kernels",
-            "config": {"workload": "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames, 1000-step guided DDPM, "
-                                   f"batch={B} per GPU; one step = joint+prior Unet3D(dim 64, mults 1-2-4) forward + "
-                                   "fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",
-                       "global_batch": world * B, "micro_batch": args.micro_batch, "parallelism": f"batch-shard x{world}"},
+            "metric": ("guided trajectories/sec, 2D smoke 128x128x64 @1000 DDPM steps" if s128 else
+                       "guided trajectories/sec, 2D smoke 64x64x32 @1000 DDPM steps"),
+            "value": world * B / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": modes + " (reported by the library: dpc_unet3d_modes). fp32 tensors in HBM and fp32 accumulation "
+                          "everywhere; f16x3 = each fp32 operand split into 2 fp16 terms (22 significant bits), 3 MFMAs per "
+                          "product; x6 = exact 3-way bf16 split, 6 MFMAs; f32 = native fp32 MFMA. value_exact re-times the same "
+                          "loop in x6",
+            "config": {"workload": f"{cfg_name}, 1000-step guided DDPM, batch={B} per GPU; one step = joint+prior Unet3D(dim 64, "
+                                   "mults 1-2-4) forward + fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",
+                       "global_batch": world * B, "micro_batch": mbatch, "parallelism": f"batch-shard x{world}"},
+            "world_size_seen_by_rccl": seen_world, "launcher": launcher,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sd_cpu, init_cpu[:1])
+    if not args.no_extras:
+        # ---- exact-product leg: same loop, arithmetic mode x6 (3-way bf16 split of both operands, 6 MFMAs per fp32 product)
+        del step, x
+        gd_x, _ = build_models(device, mbatch, arithmetic="x6", frames=frames, size=size)
+        step_x, x_x = make_step(gd_x)
+        sec_x, _, _, _, _ = timed_loop(ctx, step_x, min(args.steps, 5), 1, profile=False)
+        assert torch.isfinite(x_x).all()
+        if rank == 0:
+            out["value_exact"] = world * B / (STEPS_PER_TRAJECTORY * sec_x)
+            out["ms_per_step_exact"] = sec_x * 1e3
+            out["arithmetic_exact"] = gd_x.model_joint.modes
+        del gd_x, step_x, x_x
+        torch.cuda.empty_cache()
+        ctx.log(t_start, f"exact-mode leg done: {sec_x * 1e3:.1f} ms/step")
+        if not s128:
+            bo = run_burgers(ctx, args, t_start, with_cpu=not args.no_cpu_baseline)
+            if rank == 0:
+                out["burgers"] = bo
+            if rank == 0 and world == 1:
+                out["smoke_evaluator"] = run_smoke_evaluator(ctx)
+                ctx.log(t_start, "evaluator leg done")
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not s128:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, args.cpu_budget * 0.8)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

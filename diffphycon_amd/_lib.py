@@ -87,6 +87,11 @@ _P, _I, _L, _Z, _D, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_doubl
 _SIGNATURES = {
     "dpc_version": (C.c_int, []),
     "dpc_last_error": (C.c_char_p, []),
+    "dpc_set_mode": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "dpc_get_mode": (C.c_char_p, [C.c_char_p]),
+    "dpc_unet3d_modes": (C.c_char_p, [_P]),
+    "dpc_unet2d_modes": (C.c_char_p, [_P]),
+    "dpc_unet3d_set_range_check": (C.c_int, [_P, _I]),
     "dpc_profile_begin": (C.c_int, []),
     "dpc_profile_begin_classes": (C.c_int, [C.c_char_p]),
     "dpc_profile_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
@@ -130,6 +135,32 @@ _SIGNATURES = {
     "dpc_smoke_advect": (C.c_int, [_P, _P, _P, _I, _D, _P]),
     "dpc_smoke_domain_tables": (C.c_int, [C.POINTER(SmokeDomain), _P, _P, _P, _P, _Z, _P]),
 }
+
+
+def set_mode(family, mode):
+    """Process-wide arithmetic mode for U-Net handles created AFTER this call (include/dpc.h: dpc_set_mode)."""
+    check(lib().dpc_set_mode(family.encode(), mode.encode()))
+
+
+def get_mode(family="all"):
+    return lib().dpc_get_mode(family.encode()).decode()
+
+
+def create_with_mode(arithmetic, create):
+    """Run `create()` (a dpc_unet*_create call) with the process-wide arithmetic mode temporarily set to `arithmetic`
+    ("f16x3" | "x6" | "f32", or a dict family -> mode); the handle captures it, the process-wide setting is restored."""
+    if arithmetic is None:
+        return create()
+    fams = ("conv", "igemm", "attn", "stem")
+    saved = {f: get_mode(f) for f in fams}
+    want = arithmetic if isinstance(arithmetic, dict) else {f: arithmetic for f in fams}
+    try:
+        for f, m in want.items():
+            set_mode(f, m)
+        return create()
+    finally:
+        for f, m in saved.items():
+            set_mode(f, m)
 
 
 def exported_symbols():

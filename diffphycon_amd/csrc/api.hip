@@ -10,14 +10,88 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+
+// ---------------------------------------------------------------- arithmetic modes
+static int parse_mode(const char* e, int dflt) {
+    if (!e || !e[0]) return dflt;
+    if ((e[0] == 'f' || e[0] == 'F') && e[1] == '3') return 0;                  // "f32"
+    if (e[0] == 'x' || e[0] == 'X' || e[0] == 'b' || e[0] == 'B') return 1;      // "x6" / "bf16x6"
+    if ((e[0] == 'f' || e[0] == 'F' || e[0] == 'h') && e[1] == '1') return 2;   // "f16x3"
+    return -1;
+}
+static Modes& global_modes_ref() {
+    static Modes m = [] {
+        Modes v;
+        auto rd = [](const char* name) { const int r = parse_mode(getenv(name), 2); return r < 0 ? 2 : r; };
+        v.conv = rd("DPC_CONV_MODE"); v.igemm = rd("DPC_IGEMM_MODE"); v.attn = rd("DPC_ATTN_MODE"); v.stem = rd("DPC_STEM_MODE");
+        return v;
+    }();
+    return m;
+}
+static thread_local const Modes* g_scope = nullptr;
+Modes modes_global() { return global_modes_ref(); }
+const Modes& modes_current() { return g_scope ? *g_scope : global_modes_ref(); }
+ModeScope::ModeScope(const Modes& m) : prev_(g_scope), cur_(m) { g_scope = &cur_; }
+ModeScope::~ModeScope() { g_scope = prev_; }
+const char* mode_name(int mode) { return mode == 0 ? "f32" : (mode == 1 ? "x6" : "f16x3"); }
+std::string modes_string(const Modes& m) {
+    return std::string("conv=") + mode_name(m.conv) + ",igemm=" + mode_name(m.igemm) + ",attn=" + mode_name(m.attn) +
+           ",stem=" + mode_name(m.stem);
+}
+static thread_local RangeCheck* g_range = nullptr;
+RangeCheck* range_check_current() { return g_range; }
+RangeCheckScope::RangeCheckScope(RangeCheck* rc) : prev_(g_range) { g_range = rc; }
+RangeCheckScope::~RangeCheckScope() { g_range = prev_; }
+int range_check_note(const float* a0, long long rows0, int C0, const float* a1, long long rows1, int C1, const float* in_coef,
+                     long long rows_per_sample, hipStream_t s) {
+    RangeCheck* rc = g_range;
+    if (!rc || !rc->on || !rc->flag) return DPC_OK;
+    rc->names.push_back(rc->cur);
+    const int id = (int)rc->names.size();
+    const float limit = 65504.f / 16.f;
+    if (a0 && C0 > 0)
+        if (int r = launch_range_check(a0, rows0, C0, in_coef, rows_per_sample, limit, rc->flag, id, s)) return r;
+    if (a1 && C1 > 0)
+        if (int r = launch_range_check(a1, rows1, C1, nullptr, 0, limit, rc->flag, id, s)) return r;
+    return DPC_OK;
+}
+int conv_mode_default() { return modes_current().conv; }
+int igemm_mode_default() { return modes_current().igemm; }
 }  // namespace dpc
 
 using namespace dpc;
 
 extern "C" {
 
-int dpc_version(void) { return 100; }
+int dpc_version(void) { return 101; }
 const char* dpc_last_error(void) { return g_err.c_str(); }
+
+int dpc_set_mode(const char* family, const char* mode) {
+    DPC_REQUIRE(family && mode, "set_mode: null argument");
+    const int m = parse_mode(mode, -1);
+    DPC_REQUIRE(m >= 0, std::string("set_mode: unknown mode '") + mode + "' (f32 | x6 | f16x3)");
+    Modes& g = global_modes_ref();
+    const std::string f(family);
+    if (f == "conv") g.conv = m;
+    else if (f == "igemm") g.igemm = m;
+    else if (f == "attn") g.attn = m;
+    else if (f == "stem") g.stem = m;
+    else if (f == "all") g.conv = g.igemm = g.attn = g.stem = m;
+    else return fail(DPC_ERR_ARG, "set_mode: unknown op family '" + f + "' (conv | igemm | attn | stem | all)");
+    return DPC_OK;
+}
+
+const char* dpc_get_mode(const char* family) {
+    static thread_local std::string buf;
+    const Modes g = modes_global();
+    const std::string f(family ? family : "all");
+    if (f == "conv") return mode_name(g.conv);
+    if (f == "igemm") return mode_name(g.igemm);
+    if (f == "attn") return mode_name(g.attn);
+    if (f == "stem") return mode_name(g.stem);
+    buf = modes_string(g);
+    return buf.c_str();
+}
 
 int dpc_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z, const float* init,
                           const float* rescaler, float* x_next, float* x0_out, const dpc_step_coef* coef, int B,

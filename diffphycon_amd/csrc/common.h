@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/dpc.h"
 
@@ -33,6 +34,47 @@ int fail(int code, const std::string& msg);
     } while (0)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- arithmetic modes (api.hip)
+// How fp32 products are evaluated, per op family: 0 = native fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, 6 MFMAs),
+// 2 = f16x3 (2-way fp16 split, 3 MFMAs; default).  The process-wide setting (initialised from DPC_{CONV,IGEMM,ATTN,STEM}_MODE,
+// changed by dpc_set_mode) is CAPTURED by a U-Net handle when it is created; every later call on that handle runs under a
+// ModeScope with the captured values, so two handles with different modes can live side by side and an inherited
+// environment cannot change a handle after the fact.  dpc_get_mode / dpc_unet*_modes report what is active.
+struct Modes { int conv, igemm, attn, stem; };
+Modes modes_global();
+const Modes& modes_current();              // the innermost ModeScope of this thread, else the process-wide setting
+struct ModeScope {
+    explicit ModeScope(const Modes& m);
+    ~ModeScope();
+    const Modes* prev_;
+    Modes cur_;
+};
+// Opt-in activation range check of the f16x3 mode (dpc_unet*_set_range_check): the split-operand kernels clamp activations at
+// |x| > 65504 / 2^4 = 4094 (conv3f3.hip / igemm6.hip / stem7x6.hip: SA = 16).  With the check on, every f16x3 conv / implicit
+// GEMM / stem launch of a forward is preceded by a streaming pass over its input (after the fused GroupNorm+SiLU where the
+// halo staging applies one) that records the first op whose input leaves the range; the forward then FAILS instead of
+// returning a result computed from clamped activations.  Off by default (costs one extra read of every conv input).
+struct RangeCheck {
+    bool on = false;
+    int* flag = nullptr;                    // device word: 1-based index of the first offending op, INT_MAX = clean
+    std::vector<std::string> names;         // op names in launch order (index = position)
+    std::string cur;                        // name of the op about to be launched (set by the orchestrators)
+};
+RangeCheck* range_check_current();          // innermost RangeCheckScope of this thread or null
+struct RangeCheckScope {
+    explicit RangeCheckScope(RangeCheck* rc);
+    ~RangeCheckScope();
+    RangeCheck* prev_;
+};
+// input [rows][ctot] fp32 (channels [coff, coff + C) checked), optional GroupNorm coefficient table in_coef [B][C/4][5][4] with
+// rows_per_sample rows per sample; atomicMin(flag, id) when any |value| > limit or is not finite
+int launch_range_check(const float* x, long long rows, int C, const float* in_coef, long long rows_per_sample, float limit,
+                       int* flag, int id, hipStream_t s);
+int range_check_note(const float* a0, long long rows0, int C0, const float* a1, long long rows1, int C1, const float* in_coef,
+                     long long rows_per_sample, hipStream_t s);
+const char* mode_name(int mode);
+std::string modes_string(const Modes& m);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- opt-in event timing (profile.hip)
@@ -150,7 +192,9 @@ struct TattnParams {
     const float* rot_cos;   // [F][32]
     const float* rot_sin;
     const float* bias;      // [4][F][F]
-    const float* bias32;    // the same table zero-padded to [4][32][32] (bf16x6 kernel: 16-byte row loads)
+    const float* bias32;    // the same table zero-padded to [4][32][32] (bf16x6 kernel: 16-byte row loads); F <= 32 only
+    const float* brel;      // Toeplitz form [4][128]: bias[h][i][j] = brel[h][j - i + 63] (tattn3, 32 < F <= 64); null if the
+                            // table is not a function of j - i
     long long npix;         // B*HW sequences
     long long HW;
     int F;

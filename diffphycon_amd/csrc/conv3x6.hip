@@ -849,16 +849,6 @@ long long conv3x6_tiles_per_sample(int F, int H, int W) {
     return (long long)((F + TF - 1) / TF) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
 }
 
-int conv_mode_default() {
-    static const int mode = [] {
-        const char* e = getenv("DPC_CONV_MODE");
-        if (e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3') return 0;        // "f32"
-        if (e && (e[0] == 'x' || e[0] == 'X' || e[0] == 'b')) return 1;         // "x6" / "bf16x6"
-        return 2;                                                               // "f16x3" (default)
-    }();
-    return mode;
-}
-
 int launch_conv3x6(const Conv3hParams& p, hipStream_t s) {
     using namespace x6;
     DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "conv3x6: channel counts must be multiples of 4");

@@ -474,16 +474,6 @@ __global__ __launch_bounds__(256) void igemm3_reduce_kernel(const float* __restr
     *reinterpret_cast<f32x4*>(out + i) = v;
 }
 
-int igemm_mode_default() {
-    static const int mode = [] {
-        const char* e = getenv("DPC_IGEMM_MODE");
-        if (e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3') return 0;      // "f32": native fp32 MFMA (igemm.hip)
-        if (e && (e[0] == 'x' || e[0] == 'X' || e[0] == 'b')) return 1;       // "x6": bf16x6
-        return 2;                                                             // "f16x3" (default)
-    }();
-    return mode;
-}
-
 // sized for the larger (bf16x6) layout; the f16x3 layout uses 128 of the 192 bytes per (iteration, n)
 size_t igemm6_packed_bytes(int Npad, int K, int ntaps) { return (size_t)ntaps * igemm_kchunks(K) * Npad * 192; }
 

@@ -147,4 +147,39 @@ int launch_upsample2x_cl(const float* x, float* y, int BF, int H, int W, int C, 
     return DPC_OK;
 }
 
+// ---------------------------------------------------------------- f16x3 activation range check (common.h: RangeCheck)
+__global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long long n4, int C4,
+                                                          const float* __restrict__ in_coef, long long rows_per_sample,
+                                                          float limit, int* __restrict__ flag, int id) {
+    bool bad = false;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        if (in_coef) {       // the value the halo staging splits: SiLU((GN(x)) * (scale + 1) + shift)  (conv3f3.hip store_halo)
+            const long long row = i / C4;
+            const int c4 = (int)(i - row * C4);
+            const long long b = row / rows_per_sample;
+            const f32x4* cf = reinterpret_cast<const f32x4*>(in_coef) + (b * C4 + c4) * 5;
+            f32x4 y = (v - cf[0]) * cf[1] + cf[2];
+            y = y * cf[3] + cf[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
+            v = y;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= !(fabsf(v[e]) <= limit);          // also catches NaN / Inf
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMin(flag, id);      // flag starts at INT_MAX: keeps the FIRST offending op
+}
+
+int launch_range_check(const float* x, long long rows, int C, const float* in_coef, long long rows_per_sample, float limit,
+                       int* flag, int id, hipStream_t s) {
+    if (rows == 0 || C == 0) return DPC_OK;
+    DPC_REQUIRE(C % 4 == 0, "range_check: channel count must be a multiple of 4");
+    const long long n4 = rows * (C / 4);
+    const int grid = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(range_check_kernel, dim3(grid), dim3(256), 0, s, x, n4, C / 4, in_coef, rows_per_sample, limit, flag, id);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 }  // namespace dpc

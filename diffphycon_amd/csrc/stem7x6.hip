@@ -204,10 +204,7 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
 bool stem7x6_supported(int C, int k) { return k == 7 && C >= 1 && C <= 8; }
 size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }      // sized for 3 planes; f16x3 uses 64 of the 96 B
 
-static bool stem_h3() {
-    static const bool v = [] { const char* e = getenv("DPC_STEM_MODE"); return !(e && (e[0] == 'x' || e[0] == 'b')); }();
-    return v;
-}
+static bool stem_h3() { return modes_current().stem != 1; }
 
 int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     using namespace s7;

@@ -18,8 +18,8 @@ namespace dpc {
 using namespace h3;
 
 // C = 64: all four heads resident, one launch.  C = 128: the weights of two heads (128 KB) fit, so the block runs as two
-// launches over head pairs: pass 1 (heads 0, 1) writes its partial to_out sum to a workspace, pass 2 (heads 2, 3) adds it,
-// the residual and its own sum.
+// launches over head pairs: pass 1 (heads 0, 1) writes x + its partial to_out sum to a workspace, pass 2 (heads 2, 3) adds its own sum.
+
 template <int C_>
 struct T3 {
     static constexpr int C = C_, KS = C / 16, NTC = C / 32;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
                 const int i = rowmap3(r, hh);
                 const int ic = (FULL || i < F) ? i : 0;
                 const long long o = (row0 + (long long)ic * HW) * C + nt * 32 + l31;
-                res[r] = PASS == 1 ? 0.f : (PASS == 2 ? part[o] + p.x[o] : p.x[o]);
+                res[r] = PASS == 2 ? part[o] : p.x[o];      // pass 1 stores (its sum + x) into `part`: the same bits as part + x later
             }
             float* dstp = PASS == 1 ? part : p.out;
 #pragma unroll
@@ -307,7 +307,291 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
     }
 }
 
-bool tattn3_supported(int C, int F, int heads) { return (C == 64 || C == 128) && F <= 32 && heads == 4; }
+
+// ------------------------------------------------------------------------------------------------ 32 < F <= 64
+// Two 32-token tiles per sequence (BASELINE configs[4], S128: 64 frames).  Same dataflow and arithmetic; what changes:
+//  * one wave still owns one pixel, now with two row tiles: K and V of BOTH tiles are projected once per head and kept as
+//    split fp16 operands, each query tile then runs Q projection -> S^T against both key tiles -> softmax over 64 keys ->
+//    PV -> to_out.  That needs more than 256 registers per lane, so the workgroup has 4 waves (one per SIMD, 512 registers);
+//    the two tiles give every MFMA chain an independent partner to interleave with.
+//  * the [heads][F][F] bias table no longer fits next to the weights.  The reference's bias is a function of (key - query)
+//    only (RelativePositionBias, ...conv3d.py:106-112: bucket(k_pos - q_pos) -> embedding), so the LDS holds the 127-entry
+//    Toeplitz vector per head (`brel`, built and VERIFIED against the full table by dpc_unet3d_set_tables; a table that is
+//    not Toeplitz keeps the unfused kernels).  Rotary tables have 64 rows.
+//  * C = 64 keeps the output accumulators of both query tiles across the head loop (head outer, query tile inner); C = 128
+//    would need > 512 registers for that, so it runs query tile outer / head inner and re-projects K, V per query tile.
+template <int C_>
+struct T3W {
+    static constexpr int C = C_, KS = C / 16, NTC = C / 32;
+    static constexpr int NH = C == 64 ? 4 : 2;
+    static constexpr int HEAD_QKV = 3 * KS * 2048, HEAD_OUT = NTC * 2 * 2048;
+    static constexpr int QKV_RES = NH * HEAD_QKV, OUT_RES = NH * HEAD_OUT;
+    static constexpr int TS = 36;
+    static constexpr int OFF_COS = QKV_RES + OUT_RES, OFF_SIN = OFF_COS + 64 * TS * 4, OFF_BREL = OFF_SIN + 64 * TS * 4;
+    static constexpr int LDS_BYTES = OFF_BREL + NH * 128 * 4;              // 151552
+};
+
+template <int C_, int PASS>
+__global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const unsigned char* __restrict__ wq3,
+                                                         const unsigned char* __restrict__ wo3, float* __restrict__ part) {
+    using namespace t3;
+    using G = T3W<C_>;
+    constexpr int C = G::C, KS = G::KS, NTC = G::NTC, NH = G::NH, HEAD_QKV = G::HEAD_QKV, HEAD_OUT = G::HEAD_OUT;
+    constexpr int QKV_RES = G::QKV_RES, OUT_RES = G::OUT_RES, OFF_COS = G::OFF_COS, OFF_SIN = G::OFF_SIN, OFF_BREL = G::OFF_BREL;
+    constexpr int HD0 = PASS == 2 ? 2 : 0;
+    constexpr bool TILE_OUTER = true;      // C = 64 in the head-outer order needs 62 spilled registers per lane (kept for A/B runs)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int loff = l31 * 32 + hh * 16;
+    const int F = p.F;
+
+    for (int q = tid; q < QKV_RES / 16; q += 256)
+        reinterpret_cast<uint4*>(smem3)[q] = reinterpret_cast<const uint4*>(wq3 + (size_t)HD0 * HEAD_QKV)[q];
+    for (int q = tid; q < OUT_RES / 16; q += 256)
+        reinterpret_cast<uint4*>(smem3 + QKV_RES)[q] = reinterpret_cast<const uint4*>(wo3 + (size_t)HD0 * HEAD_OUT)[q];
+    {
+        float* cosW = reinterpret_cast<float*>(smem3 + OFF_COS);
+        float* sinW = reinterpret_cast<float*>(smem3 + OFF_SIN);
+        float* brelW = reinterpret_cast<float*>(smem3 + OFF_BREL);
+        for (int q = tid; q < 64 * 32; q += 256) {
+            const int r = q >> 5, c = q & 31;
+            cosW[r * TS + c] = r < F ? p.rot_cos[r * 32 + c] : 1.f;
+            sinW[r * TS + c] = r < F ? p.rot_sin[r * 32 + c] : 0.f;
+        }
+        for (int q = tid; q < NH * 128; q += 256) brelW[q] = p.brel[HD0 * 128 + q];
+    }
+    __syncthreads();
+
+    const long long HW = p.HW;
+    const long long nwaves = (long long)gridDim.x * 4;
+    const float qscale = 0.17677669529663687f;
+    const bool tokv[2] = {true, 32 + l31 < F};                 // F > 32 (launcher): tile 0 is always full
+    const int ti[2] = {l31, tokv[1] ? 32 + l31 : 0};
+    const float* brelL = reinterpret_cast<const float*>(smem3 + OFF_BREL);
+
+    auto row0_of = [&](long long g) {
+        const unsigned bq = (unsigned)g / (unsigned)HW;
+        return (long long)bq * F * HW + (long long)((unsigned)g - bq * (unsigned)HW);
+    };
+    // rotary on a 32x32 projection accumulator (lane = token, registers = head dims), tile T; `mul` = descale (* q scale)
+    auto rotary = [&](f32x16& a, int T, float mul) {
+        const unsigned char* cosL = smem3 + OFF_COS + (ti[T] * TS + 4 * hh) * 4;
+        const unsigned char* sinL = smem3 + OFF_SIN + (ti[T] * TS + 4 * hh) * 4;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosL + 32 * jj);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinL + 32 * jj);
+            const float a0 = a[4 * jj] * mul, a1 = a[4 * jj + 1] * mul, a2 = a[4 * jj + 2] * mul, a3 = a[4 * jj + 3] * mul;
+            a[4 * jj] = __fadd_rn(__fmul_rn(a0, c4.x), __fmul_rn(-a1, s4.x));
+            a[4 * jj + 1] = __fadd_rn(__fmul_rn(a1, c4.y), __fmul_rn(a0, s4.y));
+            a[4 * jj + 2] = __fadd_rn(__fmul_rn(a2, c4.z), __fmul_rn(-a3, s4.z));
+            a[4 * jj + 3] = __fadd_rn(__fmul_rn(a3, c4.w), __fmul_rn(a2, s4.w));
+        }
+    };
+
+    for (long long gp = (long long)blockIdx.x * 4 + wave; gp < p.npix; gp += nwaves) {
+        const long long row0 = row0_of(gp);
+        // ---- rows of both tiles: load, LayerNorm over channels (lane pair), scale, split
+        f16x8 xs[2][KS][2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            f32x4 xr[KS][2];
+            const float* src = p.x + (row0 + (long long)ti[T] * HW) * C + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xr[ks][q] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4 * q);
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (!tokv[T]) xr[ks][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = xr[ks][q];
+                    s += (v.x + v.y) + (v.z + v.w);
+                }
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s / (float)C;
+            float q2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 d = xr[ks][q] - mean;
+                    q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+            q2 += __shfl_xor(q2, 32, 64);
+            const float inv = 1.0f / sqrtf(q2 / (float)C + 1e-5f);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f32x4 n[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
+                    n[q] = (xr[ks][q] - mean) * inv * g * SX;
+                }
+                split8(sat16(n[0].x), sat16(n[0].y), sat16(n[0].z), sat16(n[0].w), sat16(n[1].x), sat16(n[1].y),
+                       sat16(n[1].z), sat16(n[1].w), xs[T][ks]);
+            }
+        }
+
+        // K^T (rotary applied) and V of both tiles for resident head hd, as split MFMA operands
+        auto project_kv = [&](int hd, f16x8 (&kk)[2][2][2], f16x8 (&vs)[2][2][2]) {
+            const unsigned char* Wq = smem3 + hd * HEAD_QKV;
+            f32x16 kT[2], vv[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { kT[T][r] = 0.f; vv[T][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f16x8 w[2];
+                load_w2(Wq + KS * 2048, ks, loff, w);
+                mfma3(kT[0], w, xs[0][ks]);
+                mfma3(kT[1], w, xs[1][ks]);
+                load_w2(Wq + 2 * KS * 2048, ks, loff, w);
+                mfma3(vv[0], xs[0][ks], w);
+                mfma3(vv[1], xs[1][ks], w);
+            }
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                rotary(kT[T], T, PROJ_DESCALE * SQK);
+                split_acc<true>(kT[T], 1.f, kk[T]);
+                split_acc<true>(vv[T], PROJ_DESCALE * SV, vs[T]);
+            }
+        };
+        // query tile `it` of head hd against both key tiles; adds its to_out contribution to y
+        auto attend = [&](int hd, int it, const f16x8 (&kk)[2][2][2], const f16x8 (&vs)[2][2][2], f32x16 (&y)[NTC]) {
+            const unsigned char* Wq = smem3 + hd * HEAD_QKV;
+            const unsigned char* Wo = smem3 + QKV_RES + hd * HEAD_OUT;
+            f32x16 qT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qT[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f16x8 w[2];
+                load_w2(Wq, ks, loff, w);
+                mfma3(qT, w, xs[it][ks]);
+            }
+            rotary(qT, it, qscale * (PROJ_DESCALE * SQK));
+            f32x16 st[2];
+            {
+                f16x8 qs[2][2];
+                split_acc<true>(qT, 1.f, qs);
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[jt][r] = 0.f;
+                    mfma3(st[jt], kk[jt][0], qs[0]);
+                    mfma3(st[jt], kk[jt][1], qs[1]);
+                }
+            }
+            // bias[h][i][j] = brel[h][j - i + 63]; registers 4jj .. 4jj+3 of key tile jt = keys 32jt + 8jj + 4hh .. +3
+            const float* bq = brelL + hd * 128 + 63 - (32 * it + l31) + 4 * hh;
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = 32 * jt + 8 * jj + e;             // + 4hh (folded into bq and the mask)
+                        float sv = st[jt][4 * jj + e] * (1.f / (SQK * SQK)) + bq[j];
+                        if (jt == 1 && j + 4 * hh >= F) sv = -INFINITY;
+                        st[jt][4 * jj + e] = sv;
+                        m = fmaxf(m, sv);
+                    }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __expf(st[jt][r] - m);
+                    st[jt][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 32, 64);
+            f32x16 oT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                f16x8 ps[2][2];
+                split_acc<false>(st[jt], SP, ps);
+                mfma3(oT, vs[jt][0], ps[0]);
+                mfma3(oT, vs[jt][1], ps[1]);
+            }
+            f16x8 os[2][2];
+            split_acc<true>(oT, (SO / (SP * SV)) / l, os);
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f16x8 w[2];
+                    load_w2(Wo, nt * 2 + s, loff, w);
+                    mfma3(y[nt], os[s], w);
+                }
+        };
+        auto store_tile = [&](int it, const f32x16 (&y)[NTC]) {
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                float res[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = 32 * it + rowmap3(r, hh);
+                    const int ic = i < F ? i : 0;
+                    const long long o = (row0 + (long long)ic * HW) * C + nt * 32 + l31;
+                    res[r] = PASS == 2 ? part[o] : p.x[o];
+                }
+                float* dstp = PASS == 1 ? part : p.out;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = 32 * it + rowmap3(r, hh);
+                    if (i < F) dstp[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+                }
+                asm volatile("" ::: "memory");       // keep the next column tile's residual loads behind these stores (registers)
+            }
+        };
+
+        if constexpr (!TILE_OUTER) {
+            f32x16 y[2][NTC];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[it][nt][r] = 0.f;
+#pragma unroll 1
+            for (int hd = 0; hd < NH; ++hd) {
+                f16x8 kk[2][2][2], vs[2][2][2];
+                project_kv(hd, kk, vs);
+                attend(hd, 0, kk, vs, y[0]);
+                attend(hd, 1, kk, vs, y[1]);
+            }
+            store_tile(0, y[0]);
+            store_tile(1, y[1]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                f32x16 y[NTC];
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y[nt][r] = 0.f;
+#pragma unroll 1
+                for (int hd = 0; hd < NH; ++hd) {
+                    f16x8 kk[2][2][2], vs[2][2][2];
+                    project_kv(hd, kk, vs);
+                    attend(hd, it, kk, vs, y);
+                }
+                store_tile(it, y);
+            }
+        }
+    }
+}
+
+bool tattn3_supported(int C, int F, int heads) { return (C == 64 || C == 128) && F <= 64 && heads == 4; }
 size_t tattn3_workspace_bytes(int C, long long rows) { return C == 128 ? (size_t)rows * C * sizeof(float) : 0; }
 
 template <int C, int PASS>
@@ -324,10 +608,22 @@ static void launch_t3(const TattnParams& p, const unsigned char* wq3, const unsi
     else hipLaunchKernelGGL((tattn3_kernel<C, false, PASS>), dim3((unsigned)grid), dim3(512), LDS, s, p, wq3, wo3, part);
 }
 
+template <int C, int PASS>
+static void launch_t3w(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, float* part, long long grid,
+                       hipStream_t s) {
+    constexpr int LDS = T3W<C>::LDS_BYTES;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)tattn3w_kernel<C, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once = true;
+    }
+    hipLaunchKernelGGL((tattn3w_kernel<C, PASS>), dim3((unsigned)grid), dim3(256), LDS, s, p, wq3, wo3, part);
+}
+
 int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, void* workspace,
                   hipStream_t s) {
     DPC_REQUIRE(tattn3_supported(C, p.F, 4), "tattn3: unsupported shape");
-    DPC_REQUIRE(p.bias32, "tattn3: padded bias table missing");
+    DPC_REQUIRE(p.F > 32 ? p.brel != nullptr : p.bias32 != nullptr, "tattn3: bias table (padded / Toeplitz form) missing");
     DPC_REQUIRE(C == 64 || workspace, "tattn3: the C = 128 form needs its partial-sum workspace");
     if (p.npix == 0) return DPC_OK;
     DPC_REQUIRE(p.npix < (1ll << 31), "tattn3: too many sequences for one launch");
@@ -341,6 +637,18 @@ int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned
         DPC_HIP(hipGetDevice(&dev));
         DPC_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = prop.multiProcessorCount;
+    }
+    if (p.F > 32) {
+        const long long gridw = std::min<long long>((p.npix + 3) / 4, ncu);
+        if (C == 64) {
+            launch_t3w<64, 0>(p, wq3, wo3, nullptr, gridw, s);
+        } else {
+            launch_t3w<128, 1>(p, wq3, wo3, reinterpret_cast<float*>(workspace), gridw, s);
+            DPC_LAUNCH_CHECK();
+            launch_t3w<128, 2>(p, wq3, wo3, reinterpret_cast<float*>(workspace), gridw, s);
+        }
+        DPC_LAUNCH_CHECK();
+        return DPC_OK;
     }
     const long long grid = std::min<long long>((p.npix + 7) / 8, ncu);
     if (C == 64) {

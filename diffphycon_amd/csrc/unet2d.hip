@@ -23,6 +23,7 @@ struct dpc_unet2d_s {
     std::set<std::string> loaded;
     dpc::DevBuf t_freq;
     bool have_tables = false, finalized = false;
+    dpc::Modes modes{2, 2, 2, 2};                                  // captured at create time (common.h: Modes)
     bool taps_on = false;
     struct Tap { std::unique_ptr<dpc::DevBuf> buf; size_t floats = 0; };
     std::map<std::string, Tap> taps;
@@ -331,6 +332,7 @@ int dpc_unet2d_create(const dpc_unet2d_cfg* cfg, dpc_unet2d_t* out) {
     DPC_REQUIRE(cfg->groups >= 1, "unet2d: groups");
     auto* h = new dpc_unet2d_s();
     h->cfg = *cfg;
+    h->modes = modes_global();
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
     for (int i = 0; i < cfg->n_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);
@@ -343,6 +345,7 @@ void dpc_unet2d_destroy(dpc_unet2d_t h) { delete h; }
 int dpc_unet2d_load(dpc_unet2d_t h, const char* name_c, const float* w, const int64_t* shape, int ndim,
                     dpc_stream_t stream) {
     DPC_REQUIRE(h && name_c && w && shape && ndim >= 1 && ndim <= 4, "unet2d_load: bad argument");
+    ModeScope mode_scope(h->modes);
     hipStream_t s = (hipStream_t)stream;
     const std::string name(name_c);
     bool known = false;
@@ -408,6 +411,7 @@ int dpc_unet2d_finalize(dpc_unet2d_t h) {
 
 size_t dpc_unet2d_workspace_bytes(dpc_unet2d_t h, int B, int H, int W) {
     if (!h || B <= 0) return 0;
+    ModeScope mode_scope(h->modes);
     Runner2D r{};
     r.h = h; r.s = nullptr; r.mb = micro_batch_of2d(h, B); r.H = H; r.W = W;
     r.ar.dry = true;
@@ -419,6 +423,7 @@ int dpc_unet2d_forward(dpc_unet2d_t h, const float* x, const int64_t* t, float* 
                        size_t ws_bytes, dpc_stream_t stream) {
     DPC_REQUIRE(h && x && t && out, "unet2d_forward: null argument");
     if (!h->finalized) return fail(DPC_ERR_STATE, "unet2d_forward: call dpc_unet2d_finalize first");
+    ModeScope mode_scope(h->modes);
     const int levels = h->cfg.n_mults - 1;
     DPC_REQUIRE(H % (1 << levels) == 0 && W % (1 << levels) == 0, "unet2d_forward: H, W must be divisible by 2^(levels-1)");
     if (B == 0) return DPC_OK;
@@ -437,6 +442,12 @@ int dpc_unet2d_forward(dpc_unet2d_t h, const float* x, const int64_t* t, float* 
         if (r.ar.overflow) return fail(DPC_ERR_STATE, "unet2d_forward: arena overflow");
     }
     return DPC_OK;
+}
+
+const char* dpc_unet2d_modes(dpc_unet2d_t h) {
+    static thread_local std::string buf;
+    buf = h ? modes_string(h->modes) : std::string();
+    return buf.c_str();
 }
 
 int dpc_unet2d_debug_taps(dpc_unet2d_t h, int enable) {

@@ -20,10 +20,14 @@ struct dpc_unet3d_s {
     std::set<std::string> loaded;
     // tables
     int frames = 0;
-    dpc::DevBuf t_bias, t_bias32, t_cos, t_sin, t_freq;
+    dpc::DevBuf t_bias, t_bias32, t_brel, t_cos, t_sin, t_freq;
+    bool bias_toeplitz = false;  // the bias table is a function of (key - query) only: t_brel holds its [heads][128] form
     bool finalized = false;
+    dpc::Modes modes{2, 2, 2, 2}; // arithmetic modes captured at create time (common.h: Modes); every call runs under them
     bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 selects the unfused reference composition (A/B tests)
-    int attn_mode = 2;           // DPC_ATTN_MODE = f32 (0: fused attention on the fp32 MFMA) | x6 (1: bf16x6) | f16x3 (2, default)
+    int attn_mode = 2;           // = modes.attn: f32 (0: fused attention on the fp32 MFMA) | x6 (1: bf16x6) | f16x3 (2, default)
+    dpc::RangeCheck range;       // dpc_unet3d_set_range_check: f16x3 activation range check (common.h)
+    dpc::DevBuf range_flag;
     bool fused_gn = true;        // DPC_UNFUSED_GN=1: standalone GroupNorm passes (3 per norm) instead of the conv-fused form
     // debug taps
     bool taps_on = false;
@@ -186,6 +190,8 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         q.gn_part = gn_part; q.in_coef = in_coef;
         if (conv_mode_default() == 2) {
             q.wp = reinterpret_cast<const float*>(pc.wp3.p);
+            if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, in_coef, (long long)F * Hi * Wi, s))
+                return r;
             return launch_conv3f3(q, s);
         }
         if (conv_mode_default() == 1) {
@@ -201,6 +207,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         Conv3hParams q{};
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = reinterpret_cast<const float*>(pc.wp3.p); q.bias = bias; q.out = out;
         q.B = 1; q.F = BF; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = (pc.K + 15) / 16; q.kd = 1;
+        if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, nullptr, 0, s)) return r;
         return launch_conv3f3(q, s);
     }
     IgemmParams p{};
@@ -213,7 +220,11 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
     for (int i = 0; i < 32; ++i) { p.tdf[i] = pc.tdf[i]; p.tdh[i] = pc.tdh[i]; p.tdw[i] = pc.tdw[i]; }
     p.M = (long long)BF * Ho * Wo;
     p.gn_raw = gn_raw; p.gn_coef = gn_coef; p.gn_rows = (long long)F * Ho * Wo;
-    if (pc.wp6g.p) return launch_igemm6(p, pc.wp6g.p, s);
+    if (pc.wp6g.p) {
+        if (igemm_mode_default() == 2 && !ln_stats)      // (a LayerNorm prologue normalises the operand before the split)
+            if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, nullptr, 0, s)) return r;
+        return launch_igemm6(p, pc.wp6g.p, s);
+    }
     return launch_igemm(p, s);
 }
 
@@ -241,6 +252,7 @@ struct Runner {
     }
     const PackedConv* conv(const std::string& n) {
         if (dry()) return nullptr;
+        if (RangeCheck* rq = range_check_current()) rq->cur = n;
         auto it = h->conv.find(n);
         if (it == h->conv.end()) { rc = fail(DPC_ERR_STATE, "missing packed weight " + n); return nullptr; }
         return it->second.get();
@@ -391,16 +403,19 @@ struct Runner {
         const long long P = (long long)mb * F * Hl * Wl;
         const int HD = h->cfg.attn_heads * 32;
         const long long HWl = (long long)Hl * Wl;
-        if (temporal && h->fused_attn && tattn_fused_supported(C, F, h->cfg.attn_heads)) {
+        const bool use_t3 = temporal && h->fused_attn && h->attn_mode == 2 && tattn3_supported(C, F, h->cfg.attn_heads) &&
+                            (F <= 32 || h->bias_toeplitz);
+        if (temporal && h->fused_attn && (use_t3 || tattn_fused_supported(C, F, h->cfg.attn_heads))) {
             TattnParams tp{};
             tp.x = x; tp.out = x; tp.gamma = raw(p + ".fn.norm.gamma"); tp.wqkv = raw(p + ".fn.fn.fn.to_qkv.weight");
             tp.wout = raw(p + ".fn.fn.fn.to_out.weight"); tp.rot_cos = h->t_cos.f(); tp.rot_sin = h->t_sin.f();
             tp.bias = h->t_bias.f(); tp.bias32 = h->t_bias32.f(); tp.npix = (long long)mb * HWl; tp.HW = HWl; tp.F = F;
+            tp.brel = h->bias_toeplitz ? h->t_brel.f() : nullptr;
             const float* q6 = raw_opt(p + ".fn.fn.fn.to_qkv.weight#x6");
             const float* o6 = raw_opt(p + ".fn.fn.fn.to_out.weight#x6");
             const float* q3 = raw_opt(p + ".fn.fn.fn.to_qkv.weight#h3");
             const float* o3 = raw_opt(p + ".fn.fn.fn.to_out.weight#h3");
-            if (h->attn_mode == 2 && tattn3_supported(C, F, h->cfg.attn_heads)) {
+            if (use_t3) {
                 const size_t m3 = ar.mark();
                 void* ws3 = ar.alloc(tattn3_workspace_bytes(C, P));        // (allocated in the dry run as well)
                 if (q3 && o3)
@@ -465,6 +480,10 @@ struct Runner {
             sp.bias = raw("init_conv.bias"); sp.out = X0; sp.BF = mb * F; sp.F = F; sp.C = c.channels; sp.H = H; sp.W = W;
             sp.Ctot = x_ctot; sp.c_off = x_coff;
             sp.N = dim; sp.Npad = h->stem_npad; sp.kchunks = h->stem_kchunks; sp.M = P0;
+            if (!dry() && h->stem_wp6 && h->modes.stem == 2) {
+                if (RangeCheck* rq = range_check_current()) rq->cur = "init_conv.weight";
+                RUN(range_check_note(x_in, (long long)mb * F * x_ctot * H * W / 4, 4, nullptr, 0, 0, nullptr, 0, s));
+            }
             if (!dry() && h->stem_wp6) RUN(launch_stem7x6(sp, h->stem_wp6->p, s));
             else RUN(launch_stem(sp, s));
         }
@@ -572,8 +591,9 @@ int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out) {
     DPC_REQUIRE(cfg->channels >= 1 && cfg->channels <= 255, "unet3d: channels");
     auto* h = new dpc_unet3d_s();
     h->cfg = *cfg;
+    h->modes = modes_global();
+    h->attn_mode = h->modes.attn;
     if (const char* e = getenv("DPC_UNFUSED_ATTN")) h->fused_attn = !(e[0] == '1');
-    if (const char* e = getenv("DPC_ATTN_MODE")) h->attn_mode = (e[0] == 'x' || e[0] == 'b') ? 1 : ((e[0] == 'f' && e[1] == '3') ? 0 : 2);
     if (const char* e = getenv("DPC_UNFUSED_GN")) h->fused_gn = !(e[0] == '1');
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
@@ -587,6 +607,7 @@ void dpc_unet3d_destroy(dpc_unet3d_t h) { delete h; }
 int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const int64_t* shape, int ndim,
                     dpc_stream_t stream) {
     DPC_REQUIRE(h && name_c && w && shape && ndim >= 1 && ndim <= 5, "unet3d_load: bad argument");
+    ModeScope mode_scope(h->modes);
     hipStream_t s = (hipStream_t)stream;
     const std::string name(name_c);
     const auto exp = expected_names(h->cfg, h->dims);
@@ -606,7 +627,7 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
         if ((rc = h->stem_wp->alloc((size_t)h->stem_kchunks * h->stem_npad * 32 * sizeof(float)))) return rc;
         if ((rc = h->stem_ktab->alloc((size_t)h->stem_kchunks * 32 * sizeof(int)))) return rc;
         rc = launch_pack_stem(w, h->stem_wp->f(), (int*)h->stem_ktab->p, N, h->stem_npad, C, k, s);
-        static const bool stem_f32 = [] { const char* e = getenv("DPC_STEM_MODE"); return e && (e[0] == 'f' || e[0] == 'F') && e[1] == '3'; }();
+        const bool stem_f32 = h->modes.stem == 0;
         h->stem_wp6.reset();
         if (!rc && !stem_f32 && stem7x6_supported(C, k)) {
             h->stem_wp6.reset(new DevBuf());
@@ -684,6 +705,28 @@ int dpc_unet3d_set_tables(dpc_unet3d_t h, int frames, const float* bias, const f
             DPC_HIP(hipMemcpy2DAsync(h->t_bias32.f() + hd * 1024, 32 * 4, bias + (size_t)hd * frames * frames, (size_t)frames * 4,
                                      (size_t)frames * 4, frames, hipMemcpyDeviceToDevice, s));
     }
+    // Toeplitz form of the bias for the long-sequence fused attention (tattn3.hip): the reference's table is
+    // emb[bucket(j - i)][h] (...conv3d.py:106-112); verify that on the host (set-up time, one small copy) instead of assuming it
+    h->bias_toeplitz = false;
+    if (heads == 4 && frames <= 64) {
+        std::vector<float> hb((size_t)heads * frames * frames), tz((size_t)4 * 128, 0.f);
+        DPC_HIP(hipMemcpyAsync(hb.data(), bias, hb.size() * 4, hipMemcpyDeviceToHost, s));
+        DPC_HIP(hipStreamSynchronize(s));
+        bool ok = true;
+        for (int hd = 0; hd < heads; ++hd) {
+            const float* b = hb.data() + (size_t)hd * frames * frames;
+            for (int r = -(frames - 1); r <= frames - 1; ++r) tz[hd * 128 + r + 63] = r >= 0 ? b[r] : b[(size_t)(-r) * frames];
+            for (int i = 0; i < frames && ok; ++i)
+                for (int j = 0; j < frames; ++j)
+                    if (b[(size_t)i * frames + j] != tz[hd * 128 + (j - i) + 63]) { ok = false; break; }
+        }
+        if (ok) {
+            if ((rc = h->t_brel.alloc(tz.size() * 4))) return rc;
+            DPC_HIP(hipMemcpyAsync(h->t_brel.p, tz.data(), tz.size() * 4, hipMemcpyHostToDevice, s));
+            DPC_HIP(hipStreamSynchronize(s));
+            h->bias_toeplitz = true;
+        }
+    }
     h->frames = frames;
     return DPC_OK;
 }
@@ -699,6 +742,7 @@ int dpc_unet3d_finalize(dpc_unet3d_t h) {
 
 size_t dpc_unet3d_workspace_bytes(dpc_unet3d_t h, int B, int F, int H, int W) {
     if (!h || B <= 0) return 0;
+    ModeScope mode_scope(h->modes);
     Runner r{};
     r.h = h; r.s = nullptr; r.mb = micro_batch_of(h, B); r.F = F; r.H = H; r.W = W;
     r.ar.dry = true;
@@ -710,6 +754,7 @@ int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int
                        float* out, int B, int F, int H, int W, void* ws, size_t ws_bytes, dpc_stream_t stream) {
     DPC_REQUIRE(h && x && t && out, "unet3d_forward: null argument");
     if (!h->finalized) return fail(DPC_ERR_STATE, "unet3d_forward: call dpc_unet3d_finalize first");
+    ModeScope mode_scope(h->modes);
     if (h->frames != F) return fail(DPC_ERR_STATE, "unet3d_forward: tables were set for a different frame count");
     const int levels = h->cfg.n_mults - 1;
     DPC_REQUIRE(H % (1 << levels) == 0 && W % (1 << levels) == 0, "unet3d_forward: H, W must be divisible by 2^(levels-1)");
@@ -720,6 +765,12 @@ int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int
     if (x_channels_total <= 0) { x_channels_total = h->cfg.channels; x_channel_offset = 0; }
     DPC_REQUIRE(x_channel_offset >= 0 && x_channel_offset + h->cfg.channels <= x_channels_total, "unet3d_forward: bad channel view");
     const long long in_per = (long long)F * x_channels_total * H * W, out_per = (long long)F * h->cfg.out_dim * H * W;
+    DPC_REQUIRE(!h->range.on || ((long long)H * W) % 4 == 0, "unet3d_forward: the range check needs H*W % 4 == 0");
+    RangeCheckScope range_scope(h->range.on ? &h->range : nullptr);
+    if (h->range.on) {
+        h->range.names.clear();
+        DPC_HIP(hipMemsetAsync(h->range_flag.p, 0x7f, 4, (hipStream_t)stream));
+    }
     for (int b0 = 0; b0 < B; b0 += mb) {
         Runner r{};
         r.h = h; r.s = (hipStream_t)stream; r.mb = std::min(mb, B - b0); r.F = F; r.H = H; r.W = W;
@@ -731,7 +782,32 @@ int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int
         if (r.rc) return r.rc;
         if (r.ar.overflow) return fail(DPC_ERR_STATE, "unet3d_forward: arena overflow");
     }
+    if (h->range.on) {                       // opt-in debugging aid: one host sync per forward
+        int first = 0;
+        DPC_HIP(hipMemcpyAsync(&first, h->range_flag.p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        DPC_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (first != 0x7f7f7f7f) {
+            const std::string nm = (first >= 1 && first <= (int)h->range.names.size()) ? h->range.names[first - 1] : "?";
+            return fail(DPC_ERR_STATE, "unet3d_forward: f16x3 activation range exceeded (|x| > 4094 or non-finite) at the input of '" +
+                                           nm + "': this arithmetic mode would clamp it; create the model with arithmetic mode x6 or f32");
+        }
+    }
     return DPC_OK;
+}
+
+int dpc_unet3d_set_range_check(dpc_unet3d_t h, int enable) {
+    DPC_REQUIRE(h, "null handle");
+    if (enable && !h->range_flag.p)
+        if (int rc = h->range_flag.alloc(4)) return rc;
+    h->range.flag = reinterpret_cast<int*>(h->range_flag.p);
+    h->range.on = enable != 0;
+    return DPC_OK;
+}
+
+const char* dpc_unet3d_modes(dpc_unet3d_t h) {
+    static thread_local std::string buf;
+    buf = h ? modes_string(h->modes) : std::string();
+    return buf.c_str();
 }
 
 int dpc_unet3d_debug_taps(dpc_unet3d_t h, int enable) {

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib
+from .diffusion_2d_smoke import _begin_noise_epoch
 
 ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start"])
 
@@ -200,6 +201,7 @@ class GaussianDiffusion(nn.Module):
         self.noise_seed = None          # None -> torch.initial_seed() at sample() time
         self.traj_offset = 0            # global index of this rank's first trajectory (batch sharding)
         self.guidance_batch = None      # batch size the guidance loss averages over (None -> local batch)
+        self.noise_epoch, self._calls = None, 0      # see diffusion_2d_smoke._begin_noise_epoch
         self._draw = 0
 
     # ------------------------------------------------------------------ noise
@@ -330,7 +332,7 @@ class GaussianDiffusion(nn.Module):
             assert "u_final" in kwargs and kwargs["u_final"] is not None
         sample_size = (batch_size, self.channels, *self.traj_size)
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
-        self._draw = 0
+        self._draw = _begin_noise_epoch(self)
         return sample_fn(sample_size, clip_denoised=clip_denoised, **kwargs)
 
 

@@ -14,7 +14,8 @@ from torch import nn
 
 from .. import _lib
 from ..model.surrogates_2d import ForceUnet, Unet  # noqa: F401  (re-exported under the reference's module path)
-from .diffusion_2d_smoke import cosine_beta_schedule, default, linear_beta_schedule, sigmoid_beta_schedule
+from .diffusion_2d_smoke import (_begin_noise_epoch, cosine_beta_schedule, default, linear_beta_schedule,
+                                 sigmoid_beta_schedule)
 
 
 def reg_theta(theta):
@@ -109,6 +110,7 @@ class GaussianDiffusion(nn.Module):
         if device is not None:
             self.to(device)
         self.noise_seed, self.traj_offset, self._draw = None, 0, 0
+        self.noise_epoch, self._calls = None, 0      # see diffusion_2d_smoke._begin_noise_epoch
 
     # ------------------------------------------------------------------ noise
     def sample_noise(self, shape, device):
@@ -300,7 +302,7 @@ class GaussianDiffusion(nn.Module):
         image_size, channels, frames = self.image_size, self.channels // 2, self.frames
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         batch_size = cond[0].shape[0]
-        self._draw = 0
+        self._draw = _begin_noise_epoch(self)
         return sample_fn((batch_size, frames, channels, image_size, image_size), design_fn, design_guidance,
                          return_all_timesteps=return_all_timesteps, cond=cond, thetas_0=thetas_0, bd_updater=bd_updater,
                          device=device)

@@ -61,6 +61,15 @@ def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
     return torch.clip(betas, 0, 0.999)
 
 
+def _begin_noise_epoch(gd):
+    """First Philox draw index of a sample() call: 4096 draws per epoch (a chain uses <= 1004).  The epoch is the call
+    count unless the caller pinned `noise_epoch` (inference scripts pin 0 and key the noise by the global trajectory id,
+    which keeps a trajectory's noise independent of batching and sharding)."""
+    epoch = gd._calls if gd.noise_epoch is None else int(gd.noise_epoch)
+    gd._calls += 1
+    return (epoch % (1 << 20)) << 12
+
+
 class SmokeGuidance:
     """The control objective of inference_2d_smoke.py:30-44 in closed form.
 
@@ -155,6 +164,8 @@ class GaussianDiffusion(nn.Module):
         # counter-based noise: keyed (seed, global trajectory index, draw)
         self.noise_seed = None          # None -> torch.initial_seed() at sample() time
         self.traj_offset = 0            # global index of this rank's first trajectory
+        self.noise_epoch = None         # None -> advances by one per sample() call (like the reference's torch RNG, two
+        self._calls = 0                 #   consecutive calls differ); an int pins it (callers that key by global trajectory)
         self._draw = 0
 
     # ------------------------------------------------------------------ noise
@@ -294,7 +305,7 @@ class GaussianDiffusion(nn.Module):
         image_size, channels, frames = self.image_size, self.channels, self.frames
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         assert batch_size == init.shape[0]
-        self._draw = 0
+        self._draw = _begin_noise_epoch(self)
         sample_size = (batch_size, frames, channels, image_size, image_size)
         return sample_fn(sample_size, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low,
                          device=device)

@@ -91,7 +91,7 @@ class Unet2D(nn.Module):
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=2, self_condition=False,
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
                  random_fourier_features=False, learned_sinusoidal_dim=16, sinusoidal_pos_emb_theta=10000,
-                 attn_dim_head=32, attn_heads=4, condition_on_residual=None, micro_batch=0):
+                 attn_dim_head=32, attn_heads=4, condition_on_residual=None, micro_batch=0, arithmetic=None):
         super().__init__()
         if self_condition or learned_variance or learned_sinusoidal_cond or random_fourier_features:
             raise NotImplementedError("only the configuration get_2d_ddpm builds is supported (train_1d_burgers.py:127-143)")
@@ -110,6 +110,7 @@ class Unet2D(nn.Module):
         self.resnet_block_groups = resnet_block_groups
         self.theta = sinusoidal_pos_emb_theta
         self.micro_batch = micro_batch
+        self.arithmetic = arithmetic          # None: the process-wide libdpc mode (default f16x3); 'x6' | 'f32' = exact products
         self._names = []
         for name, shape, kind in _param_shapes(dim, self.dim_mults, channels, self.out_dim, attn_heads, attn_dim_head):
             self._register(name, self._init(shape, kind))
@@ -158,8 +159,13 @@ class Unet2D(nn.Module):
             cfg.attn_heads, cfg.attn_dim_head = self.attn_heads, self.attn_dim_head
             cfg.groups, cfg.micro_batch = self.resnet_block_groups, self.micro_batch
             h = C.c_void_p()
-            _lib.check(_lib.lib().dpc_unet2d_create(C.byref(cfg), C.byref(h)))
+            _lib.create_with_mode(self.arithmetic, lambda: _lib.check(_lib.lib().dpc_unet2d_create(C.byref(cfg), C.byref(h))))
             self._handle = h
+
+    @property
+    def modes(self):
+        self._ensure_handle()
+        return _lib.lib().dpc_unet2d_modes(self._handle).decode()
 
     def _sync(self, device):
         L = _lib.lib()

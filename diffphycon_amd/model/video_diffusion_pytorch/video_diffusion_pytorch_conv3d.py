@@ -122,7 +122,7 @@ class _Node(nn.Module):
 class Unet3D_with_Conv3D(nn.Module):
     def __init__(self, dim, cond_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=6, attn_heads=4,
                  attn_dim_head=32, use_bert_text_cond=False, init_dim=None, init_kernel_size=7,
-                 use_sparse_linear_attn=True, block_type="resnet", resnet_groups=8, micro_batch=0):
+                 use_sparse_linear_attn=True, block_type="resnet", resnet_groups=8, micro_batch=0, arithmetic=None):
         super().__init__()
         if cond_dim is not None or use_bert_text_cond:
             raise NotImplementedError("text / cond_dim conditioning is unused on the DiffPhyCon path (…conv3d.py:366)")
@@ -137,6 +137,7 @@ class Unet3D_with_Conv3D(nn.Module):
         self.attn_heads, self.attn_dim_head = attn_heads, attn_dim_head
         self.init_kernel_size, self.resnet_groups = init_kernel_size, resnet_groups
         self.micro_batch = micro_batch
+        self.arithmetic = arithmetic          # None: the process-wide libdpc mode (default f16x3); 'x6' | 'f32' = exact products
         self._names = []
         for name, shape, kind in _param_shapes(dim, self.dim_mults, channels, self.out_dim, attn_heads, attn_dim_head,
                                                init_kernel_size):
@@ -201,7 +202,7 @@ class Unet3D_with_Conv3D(nn.Module):
             cfg.attn_heads, cfg.attn_dim_head = self.attn_heads, self.attn_dim_head
             cfg.init_kernel, cfg.groups, cfg.micro_batch = self.init_kernel_size, self.resnet_groups, self.micro_batch
             h = C.c_void_p()
-            _lib.check(L.dpc_unet3d_create(C.byref(cfg), C.byref(h)))
+            _lib.create_with_mode(self.arithmetic, lambda: _lib.check(L.dpc_unet3d_create(C.byref(cfg), C.byref(h))))
             self._handle = h
 
     def _sync(self, device, frames):
@@ -277,6 +278,18 @@ class Unet3D_with_Conv3D(nn.Module):
                                         _lib.ptr(out), B, F, H, W, C.c_void_p(self._ws.data_ptr()), self._ws.numel(),
                                         _lib.stream()))
         return out
+
+    @property
+    def modes(self):
+        """Arithmetic modes the libdpc handle captured, e.g. 'conv=f16x3,igemm=f16x3,attn=f16x3,stem=f16x3'."""
+        self._ensure_handle()
+        return _lib.lib().dpc_unet3d_modes(self._handle).decode()
+
+    def set_range_check(self, enable=True):
+        """Make forward() fail loudly when an activation leaves the range the f16x3 mode represents (|x| <= 4094) instead
+        of clamping it (include/dpc.h: dpc_unet3d_set_range_check).  A validation aid for new checkpoints; costs a sync."""
+        self._ensure_handle()
+        _lib.check(_lib.lib().dpc_unet3d_set_range_check(self._handle, int(enable)))
 
     # test hook
     def debug_taps(self, enable=True):

@@ -97,7 +97,10 @@ def get_target(target_i, f=False, device=0, dataset="free_u_f_1e5", synthetic=Fa
     """utils.py:1353-1395.  Returns the UNRESCALED target states [B, 11, 128] (or the forces with f=True).  The real
     split is an HDF5 file read through h5py (dataset/apps/burgers_h5py.py:206-255), which this image does not ship:
     without it only `synthetic=True` is available."""
-    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    if isinstance(device, int):       # the reference's default `device=0`: here the rank's current GPU (one process per GPU)
+        dev = torch.device("cuda", torch.cuda.current_device() if device == 0 and torch.cuda.is_available() else device)
+    else:
+        dev = device
     if synthetic:
         if f:
             raise NotImplementedError("synthetic targets carry no reference forces")

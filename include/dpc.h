@@ -40,6 +40,19 @@ enum dpc_status {
 int dpc_version(void);
 const char* dpc_last_error(void);
 
+/* Arithmetic mode of the GEMM-shaped op families ("conv" 3x3x3 convolutions, "igemm" implicit-GEMM ops, "attn" fused
+ * attention blocks, "stem" 7x7x7 stem; "all" sets the four): how an fp32 product is evaluated --
+ *   "f16x3" (default) 2-way fp16 operand split, 3 MFMAs per product, 22 significant operand bits;
+ *   "x6"    exact 3-way bf16 split, 6 MFMAs per product;   "f32"  the native fp32 MFMA.
+ * Accumulation and all tensors in HBM are fp32 in every mode.  The reference computes these ops in plain fp32 torch
+ * (video_diffusion_pytorch_conv3d.py:189-230; TF32 on the GPUs it targets), so "x6"/"f32" are its exact-product modes.
+ * The process-wide setting starts from the environment (DPC_{CONV,IGEMM,ATTN,STEM}_MODE) and is CAPTURED by a U-Net
+ * handle when dpc_unet*_create runs: changing it later affects only handles created afterwards.
+ * dpc_get_mode(family) returns the process-wide setting ("all"/NULL: "conv=..,igemm=..,attn=..,stem=.."), valid until the
+ * next call on the same thread; dpc_unet3d_modes / dpc_unet2d_modes return what a handle captured. */
+int dpc_set_mode(const char* family, const char* mode);
+const char* dpc_get_mode(const char* family);
+
 /* Opt-in timing of every kernel launch with HIP events on the launch stream, aggregated per kernel class
  * (bench.py's roofline leg; no counterpart in the reference, whose only stopwatch is commented out at
  * inference/inference_1d_burgers.py:287-291).  flops/bytes are ALGORITHMIC totals of the timed launches. */
@@ -108,6 +121,13 @@ int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int
 /* Debug/test hook: copy a named internal activation of the LAST micro-batch of the last forward,
  * converted to the reference's channels-first layout [mb,C,F,H,W], into dst_d (caller-sized).
  * Only active when enabled before the forward. Names as in oracle taps ("init_conv", "downs.0.0", …). */
+const char* dpc_unet3d_modes(dpc_unet3d_t h);
+/* Opt-in f16x3 activation range check: with enable != 0 every f16x3 conv / implicit-GEMM / stem launch of a forward is
+ * preceded by a pass over its input; dpc_unet3d_forward then returns DPC_ERR_STATE (naming the first such op) when an
+ * activation lies outside the range the 2^4 pre-scale keeps exact (|x| <= 4094) instead of silently clamping it.
+ * Costs one extra read of every conv input and one host sync per forward: a validation aid (e.g. the first run of a
+ * new checkpoint), not for the timed path. */
+int dpc_unet3d_set_range_check(dpc_unet3d_t h, int enable);
 int dpc_unet3d_debug_taps(dpc_unet3d_t h, int enable);
 int dpc_unet3d_get_tap(dpc_unet3d_t h, const char* name, float* dst_d, size_t dst_floats, dpc_stream_t stream);
 
@@ -207,6 +227,7 @@ size_t dpc_unet2d_workspace_bytes(dpc_unet2d_t h, int B, int H, int W);
 /* x [B,channels,H,W] fp32 (H = padded time rows 16, W = space cells 128), t [B] int64 -> out [B,out_dim,H,W] */
 int dpc_unet2d_forward(dpc_unet2d_t h, const float* x, const int64_t* t, float* out, int B, int H, int W, void* ws,
                        size_t ws_bytes, dpc_stream_t stream);
+const char* dpc_unet2d_modes(dpc_unet2d_t h);
 int dpc_unet2d_debug_taps(dpc_unet2d_t h, int enable);
 int dpc_unet2d_get_tap(dpc_unet2d_t h, const char* name, float* dst_d, size_t dst_floats, dpc_stream_t stream);
 

@@ -16,6 +16,8 @@ from diffphycon_amd.diffusion.diffusion_1d_burgers import (Trainer, cosine_beta_
 from diffphycon_amd.evaluators import burgers_numeric_solve_free  # noqa: E402
 from diffphycon_amd.utils_burgers import (mse_deviation, mse_dist_reg, ddpm_guidance_loss, burgers_metric,  # noqa: E402
                                           get_target, get_2d_ddpm)
+from diffphycon_amd import parallel  # noqa: E402
+from diffphycon_amd.diffusion.diffusion_1d_burgers import BurgersGuidance  # noqa: E402
 
 none_or_str = lambda x: None if x == "None" else x  # noqa: E731
 RESCALER = 10
@@ -108,8 +110,8 @@ def load_2dconv_model_two_ddpm(i, args):
     ddpm_uw = _load(get_2d_ddpm(args), f"./trained_models/burgers/{args.exp_id}/", args, args.checkpoint)
     unet_uw = ddpm_uw.model
     args.is_ddpm_w = True
-    args_w = use_args_w(args)
-    ddpm_w = _load(get_2d_ddpm(args_w), f"./trained_models/burgers_w/{args.exp_id__model_w}/", args_w, args.checkpoint)
+    args_w = use_args_w(args)         # the reference REBINDS args here (:199), so the prior model is loaded with ITS milestone
+    ddpm_w = _load(get_2d_ddpm(args_w), f"./trained_models/burgers_w/{args.exp_id__model_w}/", args_w, args_w.checkpoint)
     unet_w = ddpm_w.model
     args.eval_two_models, args.is_ddpm_w = True, False
     args.unet_uw, args.unet_w = unet_uw, unet_w
@@ -133,7 +135,24 @@ def diffuse_2dconv(args, custom_metric, model_i, seed=0, ret_ls=False, **kwargs)
     torch.manual_seed(seed)
     ddpm = load_2dconv_model(model_i, args)
     ddpm.noise_seed = seed
-    x = ddpm.sample(**kwargs) * RESCALER
+    # one process per GPU: rank r samples trajectories [a, b) of this batch (counter-based noise keyed by the index inside the
+    # batch, guidance normalised by the WHOLE batch), then the tiny samples [B, 2, 16, 128] are gathered once (RCCL) and every
+    # rank scores the full batch exactly as a single rank would -- no exchange inside the sampling loop
+    rank, world = getattr(args, "rank", 0), getattr(args, "world_size", 1)
+    if world > 1:
+        B = kwargs["batch_size"]
+        a, b = parallel.shard_range(B, rank, world)
+        kw = dict(kwargs)
+        kw["batch_size"] = b - a
+        kw["u_init"], kw["u_final"] = kwargs["u_init"][a:b], kwargs["u_final"][a:b]
+        g = kwargs.get("nablaJ")
+        if g is not None:
+            kw["nablaJ"] = BurgersGuidance(g.u_target[a:b], g.wu, g.wf, g.wreg, g.partially_observed)
+        ddpm.traj_offset, ddpm.guidance_batch = a, B
+        x_local = ddpm.sample(**kw)
+        x = parallel.gather_metric_rows(x_local.reshape(b - a, -1)).reshape(B, *x_local.shape[1:]) * RESCALER
+    else:
+        x = ddpm.sample(**kwargs) * RESCALER
     x_gt = burgers_numeric_solve_free(u0_from_x(x), f_from_x(x), visc=0.01, T=1.0, dt=1e-4, num_t=10)
     ddpm_mse = mse_deviation(u_from_x(x), x_gt, partially_observed=args.partially_observed).cpu()
     J_diffused, _ = custom_metric(f_from_x(x), diffused_u=u_from_x(x), evaluate_u=True)
@@ -188,6 +207,13 @@ def evaluate(model_i, args, wu=0, wf=0, wpinn=0, wf_eval=0, wu_eval=1, conv2d=Tr
 if __name__ == "__main__":
     args = parser.parse_args()
     assert torch.cuda.is_available(), "the HIP path needs a GPU"
+    args.rank, args.world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    if args.world_size > 1:                                   # torchrun, one rank per GPU; "nccl" = RCCL over xGMI
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
     if args.timesteps_override:
         import diffphycon_amd.utils_burgers as ub
         _orig = ub.GaussianDiffusion

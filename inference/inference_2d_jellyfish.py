@@ -18,6 +18,7 @@ sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffphycon_amd.diffusion.diffusion_2d_jellyfish import (ForceUnet, GaussianDiffusion, Trainer, Unet,  # noqa: E402
                                                              force_fn, reg_theta)
 from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D  # noqa: E402
+from diffphycon_amd import parallel  # noqa: E402
 from filepath import JELLYFISH_DATA_PATH  # noqa: E402
 
 
@@ -91,9 +92,21 @@ class InferencePipeline(object):
 
     def run(self, batches):
         objs = []
+        rank, world = getattr(self.args_general, "rank", 0), getattr(self.args_general, "world_size", 1)
         for sim_id, state_0, bd_0, thetas_0 in batches:
-            states, thetas = self.run_model_DDPM(state_0, bd_0, thetas_0)
-            self.save(sim_id, (states, thetas), self.results_path)
+            ids = [int(v) for v in sim_id]
+            assert ids == list(range(ids[0], ids[0] + len(ids))), "batches must hold consecutive simulation ids"
+            # one process per GPU: rank r samples simulations [a, b) of the batch; the noise is keyed by the global simulation
+            # id (Philox), so a simulation's sample does not depend on batch size or sharding, and consecutive batches differ
+            a, b = parallel.shard_range(len(ids), rank, world)
+            self.model.traj_offset, self.model.noise_epoch = ids[0] + a, 0
+            states, thetas = self.run_model_DDPM(state_0[a:b], bd_0[a:b], thetas_0[a:b])
+            if world > 1:            # final gather only (RCCL all_gather of the sampled states / angles)
+                shp = states.shape[1:]
+                states = parallel.gather_metric_rows(states.reshape(b - a, -1)).reshape(len(ids), *shp)
+                thetas = parallel.gather_metric_rows(thetas.reshape(b - a, -1)).reshape(len(ids), -1)
+            if rank == 0:
+                self.save(sim_id, (states, thetas), self.results_path)
             R = reg_theta(thetas)
             print(f"batch ids {sim_id.tolist()}: theta range [{thetas.min().item():.3f}, {thetas.max().item():.3f}], "
                   f"R(theta) mean {R.mean().item():.4e}")
@@ -160,13 +173,19 @@ def build_parser():
 if __name__ == "__main__":
     args = build_parser().parse_args()
     assert torch.cuda.is_available(), "the HIP path needs a GPU"
-    args.device = torch.device("cuda", args.gpu)
+    args.rank, args.world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    args.device = torch.device("cuda", int(os.environ["LOCAL_RANK"]) if args.world_size > 1 else args.gpu)
     torch.cuda.set_device(args.device)
+    if args.world_size > 1:                                   # torchrun, one rank per GPU; "nccl" = RCCL over xGMI
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size, device_id=args.device)
     torch.manual_seed(args.seed)
+    if not args.synthetic:
+        # fail before any checkpoint is read: the Jellyfish on-disk dataset reader is a 'next' row
+        raise NotImplementedError("the Jellyfish dataset reader is not implemented yet; run with --synthetic True")
     load_normalization(args)
     force_model, diffusion, bd_updater, design_fn = load_model(args)
     ppl = InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": args.design_guidance,
                                         "bd_updater": bd_updater}, results_path=args.inference_result_path, args_general=args)
-    if not args.synthetic:
-        raise NotImplementedError("the Jellyfish dataset reader is a 'next' row (SURVEY.md 8f-3); run with --synthetic True")
     ppl.run(synthetic_batches(args))

@@ -109,8 +109,8 @@ class InferencePipeline(object):
         J_target = -d[:, -1, -1, 0, 0]
         J_energy = d[:, :, 3:5].square().mean((1, 2, 3, 4))
         J_total = J_target + self.args_general.w_energy * J_energy
-        rows = torch.stack((J_total, J_target, J_energy, mse, n_l2), dim=1)          # [B, 5] metric rows
-        rows = parallel.gather_metric_rows(rows)                                      # RCCL all_gather when sharded
+        rows = torch.stack((J_total, J_target, J_energy, mse, n_l2), dim=1)          # [B, 5] per-trajectory metric rows
+        self.last_rows = rows               # run() gathers them ONCE after its loop (ranks may own different batch counts)
         m = rows.mean(0).cpu().numpy()
         print("J_total=J_target+w*J_energy=", m[1], "+", self.args_general.w_energy, "*", m[2], "=", m[0])
         print("mse=", m[3], "normalized_l2=", m[4])
@@ -118,13 +118,26 @@ class InferencePipeline(object):
 
     def run(self, dataloader):
         J = {k: [] for k in ("J_total", "J_target", "J_energy", "mse", "n_l2")}
+        rows = []
         for i, (state, sim_id) in enumerate(dataloader):
             print(f"Batch No.{i}")
+            ids = [int(v) for v in sim_id]
+            assert ids == list(range(ids[0], ids[0] + len(ids))), "batches must hold consecutive simulation ids"
+            # noise keyed by the global simulation id (Philox): independent of batch size and of the sharding over ranks
+            self.model[0].traj_offset, self.model[0].noise_epoch = ids[0], 0
             pred = self.run_model(state)
             print("pred shape: ", pred.shape)
             out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
+            rows.append(self.last_rows)
             for key, v in zip(J, out):
                 J[key].append(v)
+        if getattr(self.args_general, "world_size", 1) > 1:
+            # one RCCL all_gather pair for the whole run (variable row counts per rank, global trajectory order); the summary
+            # is then the mean over ALL trajectories (= the reference's mean of batch means when batches are equal-sized)
+            dev = self.args_general.device
+            local = torch.cat(rows) if rows else torch.zeros(0, 5, dtype=torch.float64, device=dev)
+            allrows = parallel.gather_metric_rows(local).mean(0).cpu().numpy()
+            J = {k: [np.array([v])] for k, v in zip(J, allrows)}
         summary = ",\n".join(f"{k}: {np.stack(v).mean(0)}" for k, v in J.items())
         print("Final results!\nNumber of upsampling times: 0\n" + summary)
         with open(os.path.join(self.results_path, "results.txt"), "a") as f:
@@ -158,7 +171,6 @@ def load_data(args):
 def main(args):
     dataloader, RESCALER = load_data(args)
     diffusion, design_fn = load_model(args, RESCALER, args.w_energy, w_init=args.w_init)
-    diffusion[0].traj_offset = parallel.shard_range(args.n_test if args.synthetic else 50, args.rank, args.world_size)[0]
     return inference(dataloader, diffusion, design_fn, args, RESCALER)
 
 

@@ -124,7 +124,7 @@ def test_philox_sampling_is_shard_invariant(g, dev):
     normalisation pinned to the global batch)."""
     c = CASES["popc"]
     gd, kwargs, D = build(g, c, dev)
-    gd.noise_seed, gd.guidance_batch = 7, 3
+    gd.noise_seed, gd.guidance_batch, gd.noise_epoch = 7, 3, 0        # epoch pinned: noise keyed by global trajectory only
     full = gd.sample(batch_size=3, **kwargs)
     parts = []
     ut = torch.from_numpy(g["u_target"])

@@ -19,17 +19,22 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _model_from_golden(g, prefix, dev, channels, dim, mults, micro_batch=0):
+def _model_from_golden(g, prefix, dev, channels, dim, mults, micro_batch=0, arithmetic=None):
     from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
-    m = Unet3D_with_Conv3D(dim=dim, dim_mults=mults, channels=channels, micro_batch=micro_batch)
+    m = Unet3D_with_Conv3D(dim=dim, dim_mults=mults, channels=channels, micro_batch=micro_batch, arithmetic=arithmetic)
     m.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)})
     return m.to(dev)
 
 
+@pytest.mark.parametrize("arithmetic", ["f16x3", "x6", "f32"])
 @pytest.mark.parametrize("tag", ["joint", "w", "wide"])
-def test_unet3d_matches_reference_fixture(tag, dev):
+def test_unet3d_matches_reference_fixture(tag, arithmetic, dev):
+    """The reference's own outputs (tiny nets, default init) in EVERY arithmetic mode of the library: f16x3 (default, 22-bit
+    operand split), x6 (exact bf16x6 products) and f32 (native fp32 MFMA) -- the mode is captured per handle."""
     g = load_golden(f"unet3d_{tag}")
-    m = _model_from_golden(g, "w:", dev, int(g["channels"]), int(g["dim"]), tuple(int(v) for v in g["dim_mults"]))
+    m = _model_from_golden(g, "w:", dev, int(g["channels"]), int(g["dim"]), tuple(int(v) for v in g["dim_mults"]),
+                           arithmetic=arithmetic)
+    assert m.modes == ",".join(f"{f}={arithmetic}" for f in ("conv", "igemm", "attn", "stem"))
     x, t = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["t"]).to(dev)
     m.debug_taps(True)
     y = m(x, t)
@@ -83,11 +88,165 @@ def test_unet3d_full_width_vs_oracle(channels, seed, dev):
         except RuntimeError:
             continue
         err = ((got - r).abs().max() / (r.abs().max() + 1e-12)).item()
-        if err > 2e-4:
+        if err > 2e-5:
             bad.append((name, err))
     assert not bad, bad
     err = ((y - ref).abs().max() / ref.abs().max()).item()
-    assert err < 2e-4, err
+    assert err < 2e-5, err                     # measured 2e-6; SURVEY 8(d) allows 1e-4
+
+
+def _oracle_parity(dev, cfg_kw, seed, shape, t, tol=2e-5, arithmetic=None):
+    """Full-width U-Net forward + every tap vs the CPU oracle (torch fp32) on seeded synthetic weights."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(**cfg_kw)
+    sd = O.synthetic_state_dict(cfg, seed=seed)
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    tt = torch.tensor(t)
+    taps = {}
+    with torch.no_grad():
+        ref = O.unet3d_forward(sd, cfg, x, tt, taps=taps)
+    m = Unet3D_with_Conv3D(arithmetic=arithmetic, **cfg_kw)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    m.debug_taps(True)
+    y = m(x.to(dev), tt.to(dev)).cpu()
+    assert y.shape == ref.shape
+    bad = []
+    for name, r in taps.items():
+        try:
+            got = m.get_tap(name, tuple(r.shape), dev).cpu()
+        except RuntimeError:
+            continue
+        err = ((got - r).abs().max() / (r.abs().max() + 1e-12)).item()
+        if err > tol:
+            bad.append((name, err))
+    assert not bad, bad
+    err = ((y - ref).abs().max() / ref.abs().max()).item()
+    assert err < tol, err
+    return m
+
+
+def test_s128_sequence_length_64_frames_vs_oracle(dev):
+    """BASELINE.json configs[4] (S128) runs 64-frame sequences: the temporal attention is length-agnostic in the reference
+    (...conv3d.py:293-352; bias buckets saturate at distance 32, :384).  dim 64, mults (1,2,4), channels 6 at F = 64 on a
+    reduced 16x16 extent against the oracle, with taps after every block (the F = 64 form of the fused temporal attention
+    at C = 64 and C = 128, the unfused chain at C = 256)."""
+    _oracle_parity(dev, dict(dim=64, dim_mults=(1, 2, 4), channels=6), 21, (1, 64, 6, 16, 16), [321])
+
+
+@pytest.mark.parametrize("frames", [40, 64])
+def test_fused_temporal_attention_long_sequences_equal_unfused(frames, dev, monkeypatch):
+    """F in (32, 64]: the fused temporal attention (two 32-token tiles per sequence) against the unfused kernel chain."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=4)
+    x = torch.randn(1, frames, 6, 8, 8, generator=torch.Generator().manual_seed(frames)).to(dev)
+    t = torch.tensor([17], device=dev)
+    outs = []
+    for unfused in ("0", "1"):
+        monkeypatch.setenv("DPC_UNFUSED_ATTN", unfused)
+        m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2), channels=6)
+        m.load_state_dict(sd)
+        outs.append(m.to(dev)(x, t))
+    err = ((outs[0] - outs[1]).abs().max() / outs[1].abs().max()).item()
+    assert err < 2e-5, (frames, err)
+
+
+def test_s128_full_size_micro_batch_and_permutation_invariance(dev):
+    """S128 extent (64 frames x 128 x 128): too large for the CPU oracle; trajectories are independent, so any micro-batching
+    and any permutation of the batch must give bit-identical per-trajectory outputs (every full-size launch shape runs twice)."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=12)
+    x = torch.randn(2, 64, 6, 128, 128, generator=torch.Generator().manual_seed(12)).to(dev)
+    t = torch.tensor([700, 20]).to(dev)
+    outs = []
+    for mb in (2, 1):
+        m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, micro_batch=mb)
+        m.load_state_dict(sd)
+        outs.append(m.to(dev)(x, t))
+        del m
+    assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
+    assert torch.equal(outs[0], outs[1])
+    m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, micro_batch=1)
+    m.load_state_dict(sd)
+    perm = torch.tensor([1, 0], device=dev)
+    assert torch.equal(m.to(dev)(x[perm], t[perm]), outs[0][perm])
+
+
+@pytest.mark.parametrize("out_dim", [4, 1])
+def test_j128_denoisers_vs_oracle(out_dim, dev):
+    """BASELINE.json configs[3] (J128): the jellyfish denoisers Unet3D(dim 64, (1,2,4), channels=7, out_dim=4 | 1) at 20 frames
+    (diffusion_2d_jellyfish.py:703-706, inference_2d_jellyfish.py load_model), reduced 16x16 extent, vs the oracle with taps."""
+    _oracle_parity(dev, dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=out_dim), 30 + out_dim, (2, 20, 7, 16, 16),
+                   [999, 40])
+
+
+def test_j128_full_size_micro_batch_and_permutation_invariance(dev):
+    """J128 extent (20 frames x 128 x 128, channels 7 -> 4): size-independent invariance as for S64 / S128."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=4)
+    sd = O.synthetic_state_dict(cfg, seed=13)
+    x = torch.randn(3, 20, 7, 128, 128, generator=torch.Generator().manual_seed(13)).to(dev)
+    t = torch.tensor([999, 500, 3]).to(dev)
+    outs = []
+    for mb in (3, 2, 1):
+        m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=4, micro_batch=mb)
+        m.load_state_dict(sd)
+        outs.append(m.to(dev)(x, t))
+    assert torch.isfinite(outs[0]).all() and outs[0].shape == (3, 20, 4, 128, 128)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    perm = torch.tensor([2, 0, 1], device=dev)
+    assert torch.equal(m(x[perm], t[perm]), outs[0][perm])
+
+
+@pytest.mark.parametrize("arithmetic", ["x6", "f32"])
+def test_unet3d_full_width_exact_modes_vs_oracle(arithmetic, dev):
+    """The exact-product modes at the real width (dim 64, mults (1,2,4), 32 frames): the kernels bench.py's value_exact runs."""
+    m = _oracle_parity(dev, dict(dim=64, dim_mults=(1, 2, 4), channels=6), 5, (1, 32, 6, 16, 16), [417], arithmetic=arithmetic)
+    assert f"conv={arithmetic}" in m.modes
+
+
+def test_activation_outside_the_f16x3_range_fails_loudly_on_request(dev):
+    """f16x3 pre-scales activations by 2^4 into fp16 and clamps beyond |x| = 4094.  With the range check enabled a forward
+    whose conv input leaves that range FAILS (naming the op) instead of returning a silently clamped result; the exact modes
+    accept the same input."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    cfg = O.Unet3DConfig(dim=16, dim_mults=(1, 2), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    x = torch.randn(1, 4, 6, 16, 16, generator=torch.Generator().manual_seed(0))
+    t = torch.tensor([3])
+    m = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=6)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    m.set_range_check(True)
+    assert torch.isfinite(m(x.to(dev), t.to(dev))).all()               # O(1) input: clean
+    big = x.clone()
+    big[0, 1, 2, 3, 4] = 5000.0                                         # one activation beyond the range at the stem input
+    with pytest.raises(RuntimeError, match="activation range exceeded.*init_conv"):
+        m(big.to(dev), t.to(dev))
+    # a large residual stream reaching a 3x3x3 conv: scale the stem so that its output is O(5000)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["init_conv.weight"] = sd2["init_conv.weight"] * 0
+    sd2["init_conv.bias"] = torch.full_like(sd2["init_conv.bias"], 5000.0)
+    m2 = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=6)
+    m2.load_state_dict(sd2)
+    m2 = m2.to(dev)
+    m2.set_range_check(True)
+    with pytest.raises(RuntimeError, match="activation range exceeded.*downs.0.0"):
+        m2(x.to(dev), t.to(dev))
+    # the exact mode represents it: same weights, matches the oracle
+    with torch.no_grad():
+        ref = O.unet3d_forward(sd2, cfg, x, t)
+    m3 = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=6, arithmetic="x6")
+    m3.load_state_dict(sd2)
+    y = m3.to(dev)(x.to(dev), t.to(dev)).cpu()
+    assert ((y - ref).abs().max() / ref.abs().max()).item() < 1e-4
 
 
 def test_unet3d_full_width_32_frames_vs_oracle(dev):
@@ -115,11 +274,11 @@ def test_unet3d_full_width_32_frames_vs_oracle(dev):
         except RuntimeError:
             continue
         err = ((got - r).abs().max() / (r.abs().max() + 1e-12)).item()
-        if err > 2e-4:
+        if err > 2e-5:
             bad.append((name, err))
     assert not bad, bad
     err = ((y - ref).abs().max() / ref.abs().max()).item()
-    assert err < 2e-4, err
+    assert err < 2e-5, err
 
 
 def test_fused_temporal_attention_equals_unfused_composition(dev, monkeypatch):
@@ -288,8 +447,26 @@ def test_sharded_sampling_matches_single_rank(dev):
     init = torch.zeros(4, 16, 16, device=dev)
     init[:, 4:7, 4:7] = 0.5
     gd = _diffusion(g, dev, CASES["std"], timesteps=6)
-    gd.noise_seed = 99
+    gd.noise_seed, gd.noise_epoch = 99, 0          # epoch pinned: the noise is keyed by the global trajectory only
     full = gd.sample(batch_size=4, design_fn=guide, init=init)
     gd.traj_offset = 2
     half = gd.sample(batch_size=2, design_fn=guide, init=init[2:])
     assert torch.equal(full[2:], half)
+
+
+def test_consecutive_sample_calls_draw_fresh_noise(dev):
+    """Like the reference's torch RNG (diffusion_2d_smoke.py:668,707), two sample() calls on one object do not repeat
+    their noise unless the caller pins `noise_epoch`."""
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
+    from oracle import sampler_smoke as S
+    g = load_golden("smoke_sampler")
+    guide = SmokeGuidance(S.RESCALER, 0.0)
+    init = torch.zeros(2, 16, 16, device=dev)
+    gd = _diffusion(g, dev, CASES["std"], timesteps=3)
+    gd.noise_seed = 5
+    a = gd.sample(batch_size=2, design_fn=guide, init=init)
+    b = gd.sample(batch_size=2, design_fn=guide, init=init)
+    assert not torch.equal(a, b)
+    gd.noise_epoch = 0
+    c = gd.sample(batch_size=2, design_fn=guide, init=init)
+    assert torch.equal(a, c)

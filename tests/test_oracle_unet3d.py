@@ -50,3 +50,15 @@ def test_synthetic_state_dict_is_deterministic():
     x = torch.randn(1, 2, 6, 8, 8)
     y = O.unet3d_forward(a, cfg, x, torch.tensor([3]))
     assert y.shape == x.shape and torch.isfinite(y).all()
+
+
+def test_product_relative_position_bucket_matches_reference_table():
+    """The PRODUCT's host-side T5 bucket table (the one the HIP attention kernels consume) against the reference's
+    RelativePositionBias._relative_position_bucket (...conv3d.py:86-104) for 4, 20, 32 and 64 frames: integer work, bit-exact
+    (the value at distance 16 depends on fp32 log rounding)."""
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import _relative_position_bucket
+    g = load_golden("relpos_bucket")
+    for n in (4, 20, 32, 64):
+        ref = g[f"n{n}"]
+        got = _relative_position_bucket(n).numpy()
+        assert got.dtype == ref.dtype and np.array_equal(got, ref), n
