@@ -3,9 +3,10 @@ method): same flags for the sampler, `reg_theta / force_fn / load_model / Infere
 running the two space-time U-Nets on libdpc and the two 2-D surrogates on PyTorch-ROCm autograd.
 
 Not carried over: the SAC / MPC baselines and the surrogate-simulator evaluation pipeline (`sim_ppl_2d`), which are
-baselines/ evaluation code outside the sampling hot path.  `--synthetic True` (extra flag) fabricates
-initial states / boundaries / angles and random-initialises all four networks when nothing is mounted under
-JELLYFISH_DATA_PATH; the normalisation constants then default to p in [-1, 1]."""
+baselines/ evaluation code outside the sampling hot path.  Without `--synthetic True` the test split is read
+from `--dataset_path` in the reference's on-disk layout (dataset/data_2d.py Jellyfish) and the four checkpoints are loaded;
+`--synthetic True` (extra flag) fabricates initial states / boundaries / angles and random-initialises all four networks when
+nothing is mounted under JELLYFISH_DATA_PATH; the normalisation constants then default to p in [-1, 1]."""
 import argparse
 import os
 import pickle
@@ -71,6 +72,30 @@ def load_model(args):
         return torch.cat([grad_state, grad_theta.unsqueeze(2)], dim=2)
 
     return force_model, diffusion, bd_updater, design_fn
+
+
+def pad_data(state_0, bd_mask_offset_0, image_size):
+    """inference_2d_jellyfish.py:328-340: fields stored at (image_size - 2)^2 are centred in a zero image_size^2 frame."""
+    def pad(x):
+        if x.shape[2] == image_size:
+            return x
+        assert x.shape[1] == 3 and x.shape[2] == image_size - 2 and x.shape[3] == image_size - 2
+        out = torch.zeros(x.shape[0], 3, image_size, image_size)
+        out[:, :, 1:-1, 1:-1] = x
+        return out
+    return pad(state_0), pad(bd_mask_offset_0)
+
+
+def dataset_batches(args):
+    """load_data (:841-855) + the unpacking of run (:808-811): the Jellyfish test split in the reference's on-disk layout."""
+    from diffphycon_amd.dataset.data_2d import Jellyfish
+    ds = Jellyfish(dataset="jellyfish", dataset_path=args.dataset_path, time_steps=40, steps=args.frames, time_interval=1,
+                   is_train=False, is_testdata=args.is_testdata, only_vis_pressure=args.only_vis_pressure)
+    loader = torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=False, pin_memory=True, num_workers=0)
+    print("number of batch in test_loader: ", len(loader))
+    for state_0, thetas_0, bd_0, sim_id, _ in loader:
+        state_0, bd_0 = pad_data(state_0, bd_0, args.image_size)
+        yield sim_id, state_0, bd_0, thetas_0
 
 
 class InferencePipeline(object):
@@ -167,6 +192,7 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--synthetic", default=False, type=eval)
     p.add_argument("--timesteps", default=1000, type=int, help="debug: shorter diffusion chain")
+    p.add_argument("--is_testdata", default=True, type=bool, help="50-simulation test split (reference default)")
     return p
 
 
@@ -181,11 +207,11 @@ if __name__ == "__main__":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size, device_id=args.device)
     torch.manual_seed(args.seed)
-    if not args.synthetic:
-        # fail before any checkpoint is read: the Jellyfish on-disk dataset reader is a 'next' row
-        raise NotImplementedError("the Jellyfish dataset reader is not implemented yet; run with --synthetic True")
+    if not args.synthetic and not os.path.isdir(os.path.join(args.dataset_path, "test_data")):
+        # fail before any checkpoint is read
+        raise FileNotFoundError(f"no Jellyfish test split under {args.dataset_path}/test_data; mount it or pass --synthetic True")
     load_normalization(args)
     force_model, diffusion, bd_updater, design_fn = load_model(args)
     ppl = InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": args.design_guidance,
                                         "bd_updater": bd_updater}, results_path=args.inference_result_path, args_general=args)
-    ppl.run(synthetic_batches(args))
+    ppl.run(synthetic_batches(args) if args.synthetic else dataset_batches(args))

@@ -136,3 +136,51 @@ def test_philox_sampling_is_shard_invariant(g, dev):
         kw["u_init"], kw["u_final"] = kwargs["u_init"][b:b + 1], kwargs["u_final"][b:b + 1]
         parts.append(gd.sample(batch_size=1, **kw))
     assert torch.equal(full, torch.cat(parts))
+
+
+def test_fopc_recipe_teacher_forced_vs_reference(dev):
+    """BASELINE.json configs[0] (B-FOPC, scripts/burgers_inference_full_obs_partial_ctr.sh): joint Unet2D dim 64 (1,2,4) with
+    ONE GroupNorm group + prior Unet2D dim 32 (1,2,4,8), prior_beta 1.5, J cosine / w sigmoid_flip schedules, fully observed,
+    timesteps = 200.  Teacher-forced: the reference's x_t and noise in, its eps / x0 / x_{t-1} out (burgers_fopc.npz; the
+    weights are regenerated from the seeds stored there)."""
+    from oracle import unet2d as U
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from diffphycon_amd.diffusion import diffusion_1d_burgers as D
+    g = load_golden("burgers_fopc")
+    kw = dict(out_dim=2, channels=2, resnet_block_groups=1)
+    m_uw, m_w = Unet2D(dim=64, dim_mults=(1, 2, 4), **kw), Unet2D(dim=32, dim_mults=(1, 2, 4, 8), **kw)
+    m_uw.load_state_dict(U.synthetic_state_dict(U.Unet2DConfig(dim=64, dim_mults=(1, 2, 4), resnet_block_groups=1),
+                                                seed=int(g["seed_uw"])))
+    m_w.load_state_dict(U.synthetic_state_dict(U.Unet2DConfig(dim=32, dim_mults=(1, 2, 4, 8), resnet_block_groups=1),
+                                               seed=int(g["seed_w"])))
+    T = int(g["timesteps"])
+    gd = D.GaussianDiffusion((m_uw, m_w), seq_length=(16, 128), timesteps=T, auto_normalize=False, use_conv2d=True,
+                             temporal=True, is_condition_u0=True, is_condition_uT=True,
+                             set_unobserved_to_zero_during_sampling=False, eval_two_models=True, prior_beta=1.5,
+                             normalize_beta=False).to(dev)
+    assert gd.num_timesteps == 200
+    ut = torch.from_numpy(g["u_target"])
+    wu, wf, wreg = (float(v) for v in g["weights"])
+    guide = D.get_nablaJ(D.BurgersGuidance(ut / 10, wu, wf, wreg, None))
+    kwargs = dict(nablaJ=guide, J_scheduler=D.cosine_beta_J_schedule, w_scheduler=D.sigmoid_schedule_flip, clip_denoised=True)
+    for t in (199, 120, 37, 0):
+        x_in = torch.from_numpy(g[f"t{t}:x_in"]).to(dev)
+        tb = torch.full((x_in.shape[0],), t, device=dev, dtype=torch.long)
+        e_uw = m_uw.to(dev)(x_in, tb).cpu()
+        ref = torch.from_numpy(g[f"t{t}:eps_uw"])
+        assert ((e_uw - ref).abs().max() / ref.abs().max()).item() < 1e-4, t         # full U-Net forward: rel 1e-4
+        xw = x_in.clone()
+        xw[:, 0, 1:10, :] = 0
+        e_w = m_w.to(dev)(xw, tb).cpu()
+        ref = torch.from_numpy(g[f"t{t}:eps_w"])
+        assert ((e_w - ref).abs().max() / ref.abs().max()).item() < 1e-4, t
+        z = torch.from_numpy(g[f"t{t}:z"]).to(dev)
+        gd.sample_noise = lambda shape, device, _z=z: _z.clone()
+        out, x0, eps = gd.p_sample(x_in.clone(), t, **kwargs)
+        for name, got in (("x_out", out), ("x0", x0), ("pred_noise", eps)):
+            err = (got.cpu() - torch.from_numpy(g[f"t{t}:{name}"])).abs().max().item()
+            # SURVEY 8(d): teacher-forced step abs 1e-4 on [-1, 1]-scale tensors.  At t = 199 of the 200-step cosine schedule
+            # x0 = c1 x - c2 eps carries c2 = sqrt(1/alpha_cumprod - 1) >> 1, which amplifies the U-Net's 1e-6-class eps deviation
+            # on the un-clamped elements of x0 (and through them x_out): that step is held to the free-chain tolerance instead
+            tol = 1e-4 if (t < 150 or name == "pred_noise") else 5e-3
+            assert err < tol, (t, name, err)
