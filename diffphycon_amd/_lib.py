@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdpc.so")
+LIB_PATH = os.environ.get("DPC_LIB") or os.path.join(_HERE, "lib", "libdpc.so")     # DPC_LIB: an instrumented build (tools/)
 _lib = None
 
 

@@ -155,6 +155,7 @@ struct Conv3hParams {
     int N, Npad, kchunks;   // kchunks = ceil((C0+C1)/16)
     int dbg;                // perf attribution only (env DPC_CONV_DBG): 1 skip output stores, 2 skip halo loads, 4 skip weight loads
     int kd;                 // 0 / 3: 3x3x3 kernel; 1: (1,3,3) kernel over independent frames (conv3f3 big-tile kernel only)
+    int total_wg;           // conv3f3b persistent form: number of tile workgroups walked by a one-per-CU grid (0 = one tile per workgroup)
     // GroupNorm fusion (conv3x6 only):
     float* gn_part;         // out: per-(sample, tile, frame-pair) channel sums of the conv output [B][tiles][2][N][2] (sum, sum sq)
     const float* in_coef;   // in: GroupNorm+scale/shift coefficients of the INPUT [B][K/4][5][4] (mu, rstd*gamma, beta, scale+1,
@@ -178,7 +179,10 @@ int launch_pack_weights_x6(const float* w, void* wp, int N, int Npad, int K, hip
 // same op with a 2-way fp16 split (22-bit operands, 3 MFMAs per product; conv3f3.hip); p.wp = [27][kchunks][Npad][2][16] fp16
 int launch_conv3f3(const Conv3hParams& p, hipStream_t s);
 int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s, int ntaps = 27);   // 9: (1,3,3) kernel
-long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad);     // GroupNorm partial-sum entries per (sample, channel)
+long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad);
+// loader-wave / persistent form of the big-tile kernel (conv3f3c.hip); same GroupNorm partial-sum layout
+bool conv3f3c_supported(const Conv3hParams& p);
+int launch_conv3f3c(const Conv3hParams& p, hipStream_t s);     // GroupNorm partial-sum entries per (sample, channel)
 // 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6), 2: f16x3 split (conv3f3); env DPC_CONV_MODE=f32|x6|f16x3, default f16x3
 int conv_mode_default();
 

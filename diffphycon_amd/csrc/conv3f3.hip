@@ -288,7 +288,7 @@ constexpr int TH8 = 8, HH8 = TH8 + 2;
 // KD = 3: the 3x3x3 convolution.  KD = 1: a (1,3,3) convolution -- the 2-D U-Net's 3x3 convs with the batch on the frame
 // axis (no coupling between frames: 9 taps, no frame halo).  Partial frame tiles are allowed (F need not divide), so the
 // kernel choice never depends on the batch size.
-template <int BN, int KD>
+template <int BN, int KD, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     using namespace f3b;
     constexpr int WM = BN == 64 ? 4 : 2, WN = 4 / WM, MT = 4, NT = 2;
@@ -302,9 +302,15 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hh = lane >> 5;
     const int ntn = p.Npad / BN;
     const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH8 - 1) / TH8, ntw = (p.W + TW - 1) / TW;
-    int bid = blockIdx.x;
+    // Persistent form (p.total_wg > gridDim.x): the grid is one workgroup per CU (a multiple of 8) and every workgroup walks
+    // its XCD's share of the tiles, so a CU never waits for a workgroup to drain and the next one to be dispatched.
+    const int nb = PERSIST ? p.total_wg : (int)gridDim.x;
+    int wg = blockIdx.x;
+    do {
+    if (PERSIST && wg != (int)blockIdx.x) __syncthreads();          // the previous tile's last taps still read the halo
+    int bid = wg;
     {   // XCD-aware order: consecutive tiles (shared halo planes, same weights) land on the same XCD's L2
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int n0 = (bid % ntn) * BN;
@@ -531,9 +537,22 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
         }
     }
 #ifdef DPC_CONV_STAMPS
-    if (lane == 0)
-        for (int i = 1; i < nstamp; ++i) p.out[((long long)blockIdx.x * 4 + wave) * 16 + i] = (float)(tstamp[i] - tstamp[i - 1]);
+    {   // per-wave records at a stride of 32 floats: [1..15] stage deltas, [16..21] raw 32-bit words: start, end (s_memtime lo/hi),
+        // HW_ID, XCC_ID -- tools/conv_stamps.py rebuilds the per-CU timeline (gaps between consecutive workgroups) from them
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            float* rec = p.out + ((long long)wg * 4 + wave) * 32;
+            for (int i = 1; i < nstamp; ++i) rec[i] = (float)(tstamp[i] - tstamp[i - 1]);
+            rec[15] = (float)(tend - tstamp[nstamp - 1]);         // epilogue
+            unsigned* ru = reinterpret_cast<unsigned*>(rec);
+            ru[16] = (unsigned)tstamp[0]; ru[17] = (unsigned)(tstamp[0] >> 32);
+            ru[18] = (unsigned)tend; ru[19] = (unsigned)(tend >> 32);
+            ru[20] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+            ru[21] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+        }
+    }
 #endif
+    } while (PERSIST && (wg += gridDim.x) < nb);   // persistent tile loop
 }
 
 // which tiling a launch uses: 0 = (2 x 2)-accumulator kernel on 4x4x8 tiles, 1 = 8x4x8 tiles (64-wide), 2 = big-tile kernel
@@ -577,6 +596,7 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     const bool flat = p.kd == 1;                 // (1,3,3) convolution: big-tile kernel only
     DPC_REQUIRE(!flat || (p.H % 8 == 0 && p.W % 8 == 0), "conv3f3: the (1,3,3) form needs H % 8 == 0 and W % 8 == 0");
     const int variant = flat ? 2 : conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
+    if (variant == 2 && !flat && conv3f3c_supported(pd)) return launch_conv3f3c(pd, s);     // loader-wave / persistent form
     if (variant == 2) {
         const int tf = wide ? 4 : 8;
         const long long tiles = (long long)p.B * ((p.F + tf - 1) / tf) * (p.H / 8) * (p.W / 8);
@@ -587,15 +607,32 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
         if (!once) {
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 12 * PST));
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 12 * PST));
+            DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 10 * 12 * PST));
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 10 * 12 * PST));
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 10 * 12 * PST));
             once = true;
         }
+        static const int persist = [] { const char* e = getenv("DPC_CONV3F3_PERSIST"); return e ? atoi(e) : 0; }();
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            DPC_HIP(hipGetDevice(&dev));
+            DPC_HIP(hipGetDeviceProperties(&prop, dev));
+            ncu = prop.multiProcessorCount / 8 * 8;
+        }
+        long long grid_l = grid;
+        pd.total_wg = 0;
+        if (persist && !flat && grid > ncu) { pd.total_wg = (int)grid; grid_l = ncu; }
         if (flat) {
             if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128, 1>), dim3((unsigned)grid), dim3(256), lds, s, pd);
             else hipLaunchKernelGGL((conv3f3b_kernel<64, 1>), dim3((unsigned)grid), dim3(256), lds, s, pd);
         } else {
-            if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128, 3>), dim3((unsigned)grid), dim3(256), lds, s, pd);
+            if (pd.total_wg) {
+                if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128, 3, true>), dim3((unsigned)grid_l), dim3(256), lds, s, pd);
+                else hipLaunchKernelGGL((conv3f3b_kernel<64, 3, true>), dim3((unsigned)grid_l), dim3(256), lds, s, pd);
+            } else if (wide) hipLaunchKernelGGL((conv3f3b_kernel<128, 3>), dim3((unsigned)grid), dim3(256), lds, s, pd);
             else hipLaunchKernelGGL((conv3f3b_kernel<64, 3>), dim3((unsigned)grid), dim3(256), lds, s, pd);
         }
         DPC_LAUNCH_CHECK();

@@ -1,0 +1,27 @@
+"""Build an instrumented copy of the library next to the product build:
+    python tools/build_variant.py <tag> [extra hipcc flags ...]   ->  diffphycon_amd/lib/libdpc_<tag>.so   (use with DPC_LIB=...)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diffphycon_amd import build as B  # noqa: E402
+
+tag, extra = sys.argv[1], sys.argv[2:]
+objdir = os.path.join(B.LIBDIR, "_" + tag)
+os.makedirs(objdir, exist_ok=True)
+hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+procs, objs = [], []
+for src in B.sources():
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
+    procs.append(subprocess.Popen([hipcc, *B.FLAGS, *extra, "-c", os.path.join(B.CSRC, src), "-o", obj],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    objs.append(obj)
+for p in procs:
+    out, _ = p.communicate()
+    if p.returncode:
+        raise SystemExit(out)
+lib = os.path.join(B.LIBDIR, f"libdpc_{tag}.so")
+subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+print(lib)
