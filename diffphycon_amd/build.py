@@ -8,6 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdpc.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# Kernels that must compile WITHOUT register spills: a spilling build of the 128-register implicit-GEMM kernel has (twice) given
+# batch-size dependent results at full size; the build fails instead of shipping one.
+NO_SPILL = {"igemm6.hip": ("igemm3_kernel",)}
 
 
 def sources():
@@ -33,6 +36,8 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if src in NO_SPILL:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -41,6 +46,17 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if src in NO_SPILL:
+            name, bad = None, []
+            for line in out.splitlines():
+                if "Function Name:" in line:
+                    name = line.split("Function Name:")[1].split()[0]
+                elif "VGPRs Spill:" in line and name and any(k in name for k in NO_SPILL[src]):
+                    if int(line.split("VGPRs Spill:")[1].split()[0]) != 0:
+                        bad.append(name)
+            if bad:
+                raise RuntimeError(f"{src}: register spills in {bad}: this kernel must not spill (see NO_SPILL in build.py)")
+            out = "\n".join(l for l in out.splitlines() if "-Rpass-analysis" not in l and not l.startswith(" ") )
         if verbose and out.strip():
             print(out)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

@@ -125,6 +125,7 @@ struct IgemmParams {
     const float* gn_raw;
     const float* gn_coef;
     long long gn_rows;
+    int dbg;                // debugging only (env DPC_IGEMM_DBG): 1 = scalar epilogue
 };
 // f16x3 weight packers raise this device flag when a weight leaves the fp16 range after its 2^12 pre-scale (|w| > 15.99);
 // dpc_unet*_finalize reads it (a host sync, at load time only) and fails loudly instead of computing with a clamped weight.

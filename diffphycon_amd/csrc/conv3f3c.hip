@@ -300,6 +300,9 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
             };
 #pragma unroll
             for (int tap = 0; tap < 27; ++tap) tap_body(tap);
+            // MFMA B-operand guard (see igemm6.hip): nothing may overwrite the activation fragments while the last MFMA reads them
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             if (j < 2) stamp();
             wg_barrier();                                  // next chunk's buffer is complete; this one may be overwritten
             if (j < 2) stamp();

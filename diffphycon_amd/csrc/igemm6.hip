@@ -249,7 +249,10 @@ typedef _Float16 f16x8_g __attribute__((ext_vector_type(8)));
 // 128 VGPRs so that four workgroups share a CU (4 x 37 KB LDS).  A deeper A-prefetch ring was measured slower: it costs
 // registers (fewer workgroups), and vmcnt retires in order, so the per-iteration wait for the next weight fragments also waits
 // for every younger A prefetch.
-template <int BN>
+// VEC: the vector epilogue (out_mode 0 / 2 with N % 4 == 0); !VEC: one dword per (row, channel) -- channels-first output, odd N.
+// Two instantiations instead of a run-time branch: with both epilogues in one kernel the 64-wide form needed spilled registers,
+// and a spilling build of this kernel has twice given batch-size dependent results at full size.
+template <int BN, bool VEC>
 __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace g3;
     constexpr int NT = BN / 64;
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
         const int nb = mtiles * ntn, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long m0 = (long long)(bid / ntn) * BM;
-    const int n0 = (bid % ntn) * BN;
+    const long long m0 = (long long)__builtin_amdgcn_readfirstlane(bid / ntn) * BM;      // wave-uniform: keep it in SGPRs
+    const int n0 = __builtin_amdgcn_readfirstlane((bid % ntn) * BN);
 
     // ---- per-thread A rows: 4 rows (tid/8 + 32 i), one float4 column (tid%8)*4   (identical to igemm.hip)
     const int arow = tid >> 3, acol = (tid & 7) * 4;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
     const int a_lane = (wm * 64 + l31) * RS + hh * 16;
     // split-K: this workgroup owns iterations [it0, niter) of the (tap, channel-chunk) sequence
     const int nit_all = p.ntaps * p.kchunks;
-    const int nsl = p.ksplit > 1 ? p.ksplit : 1;
+    const int nsl = (!VEC && p.ksplit > 1) ? p.ksplit : 1;
     const int it0 = (int)((long long)nit_all * blockIdx.y / nsl), niter = (int)((long long)nit_all * (blockIdx.y + 1) / nsl);
     load_a(it0);
     ldw(it0, wc);
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
     }
     // ---- epilogue (accumulator layout and output modes of igemm.hip).  Row-major loop: the output row offset -- two integer
     //      divisions in the channel-first and ConvTranspose-parity modes -- is computed once per accumulator row, not per element
-    if (p.ksplit > 1) {        // raw partial accumulators, [slice][M][N]; finished by igemm3_reduce_kernel
+    if (!VEC && p.ksplit > 1) {        // raw partial accumulators, [slice][M][N]; finished by igemm3_reduce_kernel (launched on the !VEC form)
         float* pb = p.part + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -408,6 +411,59 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
             }
         return;
     }
+    // Vector form (out_mode 0 / 2, N % 4 == 0): registers 4g .. 4g+3 of a lane are 4 consecutive rows of ONE channel; a 4 x 4
+    // transpose inside each lane quad (two DPP exchange stages, no LDS) turns them into 4 consecutive CHANNELS of one row, so
+    // output, residual and the fused GroupNorm input move as dwordx4 (16 contiguous bytes per lane; 4 x fewer memory
+    // instructions than one dword per (row, channel): this family is HBM / issue bound, the matrix pipe is ~8 % busy).
+    // The K loop keeps the activations as the MFMA *A* operand on purpose -- see DESIGN.md (B-operand hazard): the transposed
+    // operand order (activations as B) gave batch-size dependent results under load.
+    if constexpr (VEC) {
+        const int q3 = l31 & 3;
+        const long long bsmp = p.gn_raw ? m0 / p.gn_rows : 0;       // fused GroupNorm-apply residual: the tile lies inside one sample
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const long long m = m0 + wm * 64 + mt * 32 + 8 * g + 4 * hh + q3;      // this lane's row after the transpose
+                long long orow;
+                if (p.out_mode == 0) {
+                    orow = m * p.N;
+                } else {
+                    const long long mm = m < p.M ? m : 0;
+                    const long long bf = mm / HoWo;
+                    const int hw = (int)(mm - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
+                    orow = ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float x[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = acc[mt][nt][4 * g + e];
+                    {   // 4 x 4 transpose across the lane quad: x[j] of lane L  <-  x[L] of lane j
+                        const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+#define DPC_QUAD_XCHG(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+                        const float r0 = DPC_QUAD_XCHG(b0 ? x[0] : x[1], 0xB1), r1 = DPC_QUAD_XCHG(b0 ? x[2] : x[3], 0xB1);   // quad_perm [1,0,3,2]
+                        const float y0 = b0 ? r0 : x[0], y1 = b0 ? x[1] : r0, y2 = b0 ? r1 : x[2], y3 = b0 ? x[3] : r1;
+                        const float s0 = DPC_QUAD_XCHG(b1 ? y0 : y2, 0x4E), s1 = DPC_QUAD_XCHG(b1 ? y1 : y3, 0x4E);           // quad_perm [2,3,0,1]
+#undef DPC_QUAD_XCHG
+                        x[0] = b1 ? s0 : y0; x[2] = b1 ? y2 : s0; x[1] = b1 ? s1 : y1; x[3] = b1 ? y3 : s1;
+                    }
+                    const int n = n0 + wn * (BN / 2) + nt * 32 + (l31 & ~3);
+                    if (m >= p.M || n >= p.N) continue;
+                    f32x4 v = f32x4{x[0], x[1], x[2], x[3]} * DESCALE;
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.N + n);
+                    if (p.gn_raw) {
+                        const f32x4* cf = reinterpret_cast<const f32x4*>(p.gn_coef) + (bsmp * (p.N >> 2) + (n >> 2)) * 5;
+                        f32x4 y = (*reinterpret_cast<const f32x4*>(p.gn_raw + m * p.N + n) - cf[0]) * cf[1] + cf[2];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
+                        v += y;
+                    }
+                    *reinterpret_cast<f32x4*>(p.out + orow + n) = v;
+                }
+            }
+    } else {
     float bv[NT];
     int ncol[NT];
 #pragma unroll
@@ -458,6 +514,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
             }
         }
     }
+    }   // !VEC
 }
 
 // second half of a split-K launch: out = (sum of the slices in index order) * 2^-16 + bias (+ residual), [M][N] layout
@@ -522,7 +579,7 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
             IgemmParams q = p;
             q.ksplit = nsl;
             q.part = scratch;
-            hipLaunchKernelGGL(igemm3_kernel<64>, dim3((unsigned)nwg, nsl), dim3(256), lds3, s, q, (const unsigned char*)wp6);
+            hipLaunchKernelGGL((igemm3_kernel<64, false>), dim3((unsigned)nwg, nsl), dim3(256), lds3, s, q, (const unsigned char*)wp6);
             DPC_LAUNCH_CHECK();
             const long long MN = p.M * p.N;
             hipLaunchKernelGGL(igemm3_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, scratch, p.bias, p.resid,
@@ -530,11 +587,14 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
             DPC_LAUNCH_CHECK();
             return DPC_OK;
         }
+        const bool vec = (p.N & 3) == 0 && p.out_mode != 1;
         if (wide) {
-            hipLaunchKernelGGL(igemm3_kernel<128>, dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
+            if (vec) hipLaunchKernelGGL((igemm3_kernel<128, true>), dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
+            else hipLaunchKernelGGL((igemm3_kernel<128, false>), dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
         } else {
             DPC_REQUIRE(p.Npad % 64 == 0, "igemm3: Npad must be a multiple of 64");
-            hipLaunchKernelGGL(igemm3_kernel<64>, dim3(mtiles * (p.Npad / 64)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
+            if (vec) hipLaunchKernelGGL((igemm3_kernel<64, true>), dim3(mtiles * (p.Npad / 64)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
+            else hipLaunchKernelGGL((igemm3_kernel<64, false>), dim3(mtiles * (p.Npad / 64)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
         }
         DPC_LAUNCH_CHECK();
         return DPC_OK;

@@ -23,6 +23,8 @@ struct dpc_unet2d_s {
     std::set<std::string> loaded;
     dpc::DevBuf t_freq;
     bool have_tables = false, finalized = false;
+    long long ws_key[3] = {0, 0, 0};      // (B, H, W) of the last workspace dry run and its result
+    size_t ws_need = 0;
     dpc::Modes modes{2, 2, 2, 2};                                  // captured at create time (common.h: Modes)
     bool taps_on = false;
     struct Tap { std::unique_ptr<dpc::DevBuf> buf; size_t floats = 0; };
@@ -387,6 +389,7 @@ int dpc_unet2d_load(dpc_unet2d_t h, const char* name_c, const float* w, const in
     }
     if (rc == DPC_OK) h->loaded.insert(name);
     h->finalized = false;
+    h->ws_need = 0;
     return rc;
 }
 
@@ -411,12 +414,15 @@ int dpc_unet2d_finalize(dpc_unet2d_t h) {
 
 size_t dpc_unet2d_workspace_bytes(dpc_unet2d_t h, int B, int H, int W) {
     if (!h || B <= 0) return 0;
+    if (h->ws_need && h->ws_key[0] == B && h->ws_key[1] == H && h->ws_key[2] == W) return h->ws_need;
     ModeScope mode_scope(h->modes);
     Runner2D r{};
     r.h = h; r.s = nullptr; r.mb = micro_batch_of2d(h, B); r.H = H; r.W = W;
     r.ar.dry = true;
     r.forward(nullptr, nullptr, nullptr);
-    return r.ar.peak + 256;
+    h->ws_key[0] = B; h->ws_key[1] = H; h->ws_key[2] = W;
+    h->ws_need = r.ar.peak + 256;
+    return h->ws_need;
 }
 
 int dpc_unet2d_forward(dpc_unet2d_t h, const float* x, const int64_t* t, float* out, int B, int H, int W, void* ws,

@@ -23,6 +23,8 @@ struct dpc_unet3d_s {
     dpc::DevBuf t_bias, t_bias32, t_brel, t_cos, t_sin, t_freq;
     bool bias_toeplitz = false;  // the bias table is a function of (key - query) only: t_brel holds its [heads][128] form
     bool finalized = false;
+    long long ws_key[4] = {0, 0, 0, 0};   // (B, F, H, W) of the last workspace dry run and its result (a forward needs it twice)
+    size_t ws_need = 0;
     dpc::Modes modes{2, 2, 2, 2}; // arithmetic modes captured at create time (common.h: Modes); every call runs under them
     bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 selects the unfused reference composition (A/B tests)
     int attn_mode = 2;           // = modes.attn: f32 (0: fused attention on the fp32 MFMA) | x6 (1: bf16x6) | f16x3 (2, default)
@@ -681,6 +683,7 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
     }
     if (rc == DPC_OK) h->loaded.insert(name);
     h->finalized = false;
+    h->ws_need = 0;
     return rc;
 }
 
@@ -742,12 +745,15 @@ int dpc_unet3d_finalize(dpc_unet3d_t h) {
 
 size_t dpc_unet3d_workspace_bytes(dpc_unet3d_t h, int B, int F, int H, int W) {
     if (!h || B <= 0) return 0;
+    if (h->ws_need && h->ws_key[0] == B && h->ws_key[1] == F && h->ws_key[2] == H && h->ws_key[3] == W) return h->ws_need;
     ModeScope mode_scope(h->modes);
     Runner r{};
     r.h = h; r.s = nullptr; r.mb = micro_batch_of(h, B); r.F = F; r.H = H; r.W = W;
     r.ar.dry = true;
     r.forward(nullptr, nullptr, nullptr);
-    return r.ar.peak + 256;
+    h->ws_key[0] = B; h->ws_key[1] = F; h->ws_key[2] = H; h->ws_key[3] = W;
+    h->ws_need = r.ar.peak + 256;
+    return h->ws_need;
 }
 
 int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int x_channel_offset, const int64_t* t,

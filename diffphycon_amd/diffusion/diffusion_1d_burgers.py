@@ -7,6 +7,7 @@ and no per-step device sync: the reference's `t[0].item()` scheduler look-ups (:
 """
 import ctypes as C
 import math
+import os
 from collections import namedtuple
 
 import torch
@@ -203,6 +204,8 @@ class GaussianDiffusion(nn.Module):
         self.guidance_batch = None      # batch size the guidance loss averages over (None -> local batch)
         self.noise_epoch, self._calls = None, 0      # see diffusion_2d_smoke._begin_noise_epoch
         self._draw = 0
+        self.use_graph = os.environ.get("DPC_BURGERS_GRAPH", "1") != "0"     # HIP-graph replay of the denoiser forwards
+        self._graphs, self._t_static = {}, None
 
     # ------------------------------------------------------------------ noise
     def sample_noise(self, shape, device):
@@ -259,6 +262,40 @@ class GaussianDiffusion(nn.Module):
             return self.model_uw(img, t_b), self.model_w(x_w, t_b)
         return self.model(img, t_b), None
 
+    def _denoise_step(self, img, x_w, t: int):
+        """The two denoiser forwards of step t.  With `use_graph` the several hundred launches of the two Unet2D forwards are
+        captured ONCE into a HIP graph (keyed by the state buffers' addresses and shape) and replayed per step; the time step
+        is a device tensor refreshed before each replay, the state is updated in place by the sampler, so nothing else changes
+        between replays.  At B = 256 the forwards are launch-latency bound (16 x 128 images down to 1 x 8): replaying removes
+        the per-launch host cost and the gaps between launches.  Not used while per-kernel event timing is on (bench.py's
+        roofline leg): events inside a captured stream cannot be read back."""
+        B = img.shape[0]
+        if not self.use_graph:
+            return self._denoise(img, x_w, torch.full((B,), t, device=img.device, dtype=torch.long))
+        key = (img.data_ptr(), 0 if x_w is None else x_w.data_ptr(), tuple(img.shape))
+        if key not in self._graphs:
+            if len(self._graphs) >= 2:              # (two state buffers when the sampler ping-pongs; anything else: start over)
+                self._graphs.clear()
+            if self._t_static is None or self._t_static.shape[0] != B or self._t_static.device != img.device:
+                self._t_static = torch.full((B,), t, device=img.device, dtype=torch.long)
+                self._graphs.clear()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):            # eager warm-up: weight upload, workspace, one-time attribute / scratch set-up
+                for _ in range(2):
+                    self._denoise(img, x_w, self._t_static)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._denoise(img, x_w, self._t_static)
+            self._graphs[key] = (g, out)
+        self._t_static.fill_(t)
+        g, out = self._graphs[key]
+        g.replay()
+        return out
+
     @staticmethod
     def _guide(kwargs):
         nablaJ = kwargs.get("nablaJ")
@@ -307,8 +344,7 @@ class GaussianDiffusion(nn.Module):
         pingpong = torch.empty_like(img) if (guide is not None and guide.wreg != 0) else None
         for t in reversed(range(0, self.num_timesteps)):
             self._prepare(img, x_w, u0, uT)
-            t_b = torch.full((B,), t, device=device, dtype=torch.long)
-            e_uw, e_w = self._denoise(img, x_w, t_b)
+            e_uw, e_w = self._denoise_step(img, x_w, t)
             z = self.sample_noise(list(shape), device) if t > 0 else None
             coef = self._coef(t, guide, J_sched, w_sched, clip, B)
             if pingpong is None:

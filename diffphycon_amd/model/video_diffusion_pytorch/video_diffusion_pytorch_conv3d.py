@@ -208,7 +208,9 @@ class Unet3D_with_Conv3D(nn.Module):
     def _sync(self, device, frames):
         L = _lib.lib()
         self._ensure_handle()
+        changed = False
         if self._dirty or self._device != device:
+            changed = True
             sd = self.state_dict()
             for name in self._names:
                 w = sd[name].detach().to(device=device, dtype=torch.float32).contiguous()
@@ -218,6 +220,7 @@ class Unet3D_with_Conv3D(nn.Module):
             self._dirty = False
             self._device = device
         if self._frames != frames:
+            changed = True
             emb = self.state_dict()["time_rel_pos_bias.relative_attention_bias.weight"].detach().float().cpu()
             bias = emb[_relative_position_bucket(frames)].permute(2, 0, 1).contiguous()          # (:111-112)
             cos, sin = _rotary_tables(frames, min(32, self.attn_dim_head))
@@ -227,7 +230,8 @@ class Unet3D_with_Conv3D(nn.Module):
             _lib.check(L.dpc_unet3d_set_tables(self._handle, frames, *[_lib.ptr(t) for t in tabs], _lib.stream()))
             torch.cuda.current_stream().synchronize()      # tables are copied by the library before `tabs` dies
             self._frames = frames
-        _lib.check(L.dpc_unet3d_finalize(self._handle))
+        if changed:         # (finalize reads the weight-range flag back: a host sync, so only after loads -- never per forward)
+            _lib.check(L.dpc_unet3d_finalize(self._handle))
 
     def __del__(self):
         try:
