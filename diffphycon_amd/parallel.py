@@ -13,10 +13,24 @@ def shard_range(global_batch, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def init_process_group(rank, world_size, device):
+    """One process per GPU.  Backend "nccl" (= RCCL over xGMI on ROCm) unless DPC_DIST_BACKEND says otherwise ("gloo" lets
+    the sharded entry scripts be exercised with several ranks on ONE GPU: RCCL refuses two ranks on the same device)."""
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("DPC_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
+
+
 def gather_metric_rows(rows):
     """rows: [B_local, M] per rank (B_local may differ) -> [B_global, M] on every rank, in global trajectory order."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return rows
+    if dist.get_backend() == "gloo" and rows.is_cuda:          # gloo gathers host tensors
+        return gather_metric_rows(rows.cpu()).to(rows.device)
     world = dist.get_world_size()
     n = torch.tensor([rows.shape[0]], dtype=torch.long, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]

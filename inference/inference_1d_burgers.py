@@ -208,12 +208,9 @@ if __name__ == "__main__":
     args = parser.parse_args()
     assert torch.cuda.is_available(), "the HIP path needs a GPU"
     args.rank, args.world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
     if args.world_size > 1:                                   # torchrun, one rank per GPU; "nccl" = RCCL over xGMI
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size,
-                                device_id=torch.device("cuda", torch.cuda.current_device()))
+        parallel.init_process_group(args.rank, args.world_size, torch.device("cuda", torch.cuda.current_device()))
     if args.timesteps_override:
         import diffphycon_amd.utils_burgers as ub
         _orig = ub.GaussianDiffusion

@@ -200,12 +200,10 @@ if __name__ == "__main__":
     args = build_parser().parse_args()
     assert torch.cuda.is_available(), "the HIP path needs a GPU"
     args.rank, args.world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    args.device = torch.device("cuda", int(os.environ["LOCAL_RANK"]) if args.world_size > 1 else args.gpu)
+    args.device = torch.device("cuda", int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count() if args.world_size > 1 else args.gpu)
     torch.cuda.set_device(args.device)
     if args.world_size > 1:                                   # torchrun, one rank per GPU; "nccl" = RCCL over xGMI
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size, device_id=args.device)
+        parallel.init_process_group(args.rank, args.world_size, args.device)
     torch.manual_seed(args.seed)
     if not args.synthetic and not os.path.isdir(os.path.join(args.dataset_path, "test_data")):
         # fail before any checkpoint is read

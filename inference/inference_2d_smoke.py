@@ -211,13 +211,11 @@ if __name__ == "__main__":
     np.random.seed(args.seed)
     assert torch.cuda.is_available(), "the HIP path needs a GPU"
     args.rank, args.world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count()
     torch.cuda.set_device(local)
     args.device = torch.device("cuda", local)
     if args.world_size > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=args.rank, world_size=args.world_size, device_id=args.device)
+        parallel.init_process_group(args.rank, args.world_size, args.device)
     args.inference_result_subpath = os.path.join(args.inference_result_path,
                                                  datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
     print("args: ", args)

@@ -39,3 +39,66 @@ def test_jellyfish_inference_script(tmp_path):
                "--frames", "4", "--image_size", "64", "--timesteps", "3", "--inference_result_path", str(tmp_path)], ROOT)
     assert "Final results!" in out
     assert os.path.exists(os.path.join(str(tmp_path), "thetas", "0.npy"))
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank (N > 1) path
+# No multi-GPU box is available to the builder, and RCCL refuses two ranks on one device, so the SHARDED code path of the three
+# entry scripts is exercised with two ranks on cuda:0 over gloo (DPC_DIST_BACKEND=gloo; the collective itself is covered on
+# CPU by tests/test_parallel_gloo.py).  Counter-based noise keyed by the global trajectory id + the final gather must give
+# exactly the single-rank result.
+def run_ranks(n, cmd, cwd, extra_env=None):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DPC_DIST_BACKEND="gloo", **(extra_env or {}))
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port)] + cmd, cwd=cwd, env=env, capture_output=True, text=True,
+                       timeout=1200)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return p.stdout
+
+
+def _floats_after(out, key):
+    import re
+    return [float(v) for line in out.splitlines() if line.startswith(key) for v in re.findall(r"[-+]?\d*\.\d+(?:[eE][-+]?\d+)?", line)]
+
+
+def test_smoke_script_two_ranks_ragged_shards_match_single_rank(tmp_path):
+    args = ["inference/inference_2d_smoke.py", "--synthetic", "True", "--n_test", "3", "--batch_size", "1",
+            "--ddim_sampling_steps", "2"]
+    one = run(args + ["--inference_result_path", str(tmp_path / "a")], ROOT)
+    two = run_ranks(2, args + ["--inference_result_path", str(tmp_path / "b")], ROOT)        # rank 0: 2 batches, rank 1: 1 batch
+    for key in ("J_total:", "J_target:", "mse:", "n_l2:"):
+        a, b = _floats_after(one, key), _floats_after(two, key)
+        assert a and b, (key, one[-500:], two[-500:])
+        assert all(abs(x - a[-1]) <= 1e-12 * max(1.0, abs(a[-1])) for x in b), (key, a, b)
+
+
+def test_burgers_script_two_ranks_match_single_rank():
+    args = ["inference/inference_1d_burgers.py", "--dataset", "free_u_f_1e5_front_rear_quarter", "--partial_control",
+            "front_rear_quarter", "--partially_observed", "front_rear_quarter", "--train_on_partially_observed", "None",
+            "--set_unobserved_to_zero_during_sampling", "True", "--is_condition_u0", "True", "--is_condition_uT", "True",
+            "--J_scheduler", "cosine", "--dim", "16", "--dim_muls", "1", "2", "4", "--exp_id", "POPC",
+            "--dim__model_w", "16", "--dim_muls__model_w", "1", "2", "--exp_id__model_w", "POPC_w",
+            "--is_model_w", "False", "--eval_two_models", "True", "--prior_beta", "0.9", "--w_scheduler", "sigmoid_flip",
+            "--wus", "0.5", "--synthetic", "True", "--n_test_samples", "3", "--batch_size", "3", "--timesteps_override", "6"]
+    one = run(args, ROOT)
+    two = run_ranks(2, args, ROOT)                       # batch of 3 split 2 + 1; guidance normalised by the whole batch
+    for key in ("J_actual:", "Energy:"):
+        a, b = _floats_after(one, key), _floats_after(two, key)
+        assert a and b and all(x == a[-1] for x in b), (key, a, b)
+
+
+def test_jellyfish_script_two_ranks_match_single_rank(tmp_path):
+    import numpy as np
+    args = ["inference/inference_2d_jellyfish.py", "--synthetic", "True", "--batch_size", "3", "--num_batches", "1",
+            "--frames", "4", "--image_size", "64", "--timesteps", "2"]
+    run(args + ["--inference_result_path", str(tmp_path / "a")], ROOT)
+    run_ranks(2, args + ["--inference_result_path", str(tmp_path / "b")], ROOT)
+    for i in range(3):
+        for sub in ("thetas", "states"):
+            a, b = np.load(tmp_path / "a" / sub / f"{i}.npy"), np.load(tmp_path / "b" / sub / f"{i}.npy")
+            # not bit-equal: the design gradient still runs through the two torch (MIOpen / rocBLAS) surrogate U-Nets, whose
+            # kernels pick batch-size dependent reduction orders (1 ulp seen); everything on libdpc is batch invariant
+            assert np.abs(a - b).max() <= 1e-6, (sub, i, np.abs(a - b).max())
