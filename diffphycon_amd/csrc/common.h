@@ -97,6 +97,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // out[m][n] = bias[n] + resid[m][n] + sum_{tap,c} A(m,tap,c) * W(tap,c,n)
 // A rows are output points (b,f,ho,wo) of a channels-last activation; see DESIGN.md.
 struct IgemmParams {
+    float act_scale;        // f16x3 kernels: power-of-two scale applied to the activation operand before the fp16 split (0: 2^4),
+                            // undone in the epilogue; lets a caller place a tensor of any magnitude inside the fp16 window
+    float descale;          // (filled by the launcher: 1 / (act_scale * 2^12))
     const float* a0;        // source 0, channels-last [B*F, Hi, Wi, C0]
     const float* a1;        // source 1 (virtual concat along channels) or null
     int C0, C1;
@@ -146,6 +149,7 @@ int launch_pack_weights(const float* w, float* wp, int N, int Npad, int K, int n
 
 // Conv3d 3x3x3 stride 1 pad 1 with the LDS-staged halo tile (conv3h.hip); weights packed with bk = 16
 struct Conv3hParams {
+    float act_scale;        // as IgemmParams::act_scale (conv3f3 / conv3f3b; 0: 2^4)
     const float* a0;        // channels-last [B,F,H,W,C0]
     const float* a1;        // virtual concat source [B,F,H,W,C1] or null
     int C0, C1;
@@ -263,6 +267,16 @@ int launch_ln_stats(const float* x, float* stats, long long rows, int C, hipStre
 int launch_ln_apply(const float* x, const float* stats, const float* gamma, const float* resid, float* out,
                     long long rows, int C, hipStream_t s);
 size_t gn_workspace_bytes(int B, int C);
+// statistics only: stats [B][groups][2] = (mean, rstd) of x [B][R][C]
+int launch_gn_stats(const float* x, float* stats, int B, long long R, int C, int groups, void* ws, hipStream_t s);
+// backward of out = SiLU(GN(x) * (scale + 1) + shift): dx [B][R][C] and, when dss != null, d(scale | shift) [B][2C]
+size_t gn_bwd_workspace_bytes(int B, int C);
+int launch_gn_silu_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                       const float* scale_shift, float* dx, float* dss, int B, long long R, int C, int groups, void* ws,
+                       hipStream_t s);
+// backward of the channel LayerNorm y = (x - mean) * rstd * g: dx (= or +=) per row
+int launch_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, long long rows, int C, int accum,
+                  hipStream_t s);
 // out = SiLU(GN(x)*(scale+1)+shift) (+ resid); out may alias x or resid (same-element in-place)
 int launch_groupnorm_silu(const float* x, float* out, const float* resid, const float* gamma, const float* beta,
                           const float* scale_shift, int B, long long rows_per_sample, int C, int groups, void* ws,

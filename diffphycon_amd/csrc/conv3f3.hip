@@ -29,7 +29,7 @@ constexpr int HH = TH + 2, HWL = TW + 2, HWD = 12;
 constexpr int KC = 16;
 constexpr int PST = 80;                    // bytes per halo point in LDS (2 planes x 32 B + 16 pad; 5 x 16 B: odd)
 constexpr int WROW = 64;                   // bytes per output channel per (tap, chunk) in the packed weights
-constexpr float SA = 16.0f, SW = 4096.0f, DESCALE = 1.0f / 65536.0f;
+constexpr float SA = 16.0f, SW = 4096.0f;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
     unsigned char* halo = smem_f3;                      // [NSLOT][PST]
 
+    const float sa = p.act_scale != 0.f ? p.act_scale : SA;            // (uniform: scalar registers)
+    const float descale = 1.0f / (sa * SW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hh = lane >> 5;
     const int ntn = p.Npad / BN;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
         for (int i = 0; i < HLOADS; ++i) {
             if (tid + 256 * i < NLOG * 4) {
                 uint2 p1, p2;
-                split2(hreg[i] * SA, p1, p2);
+                split2(hreg[i] * sa, p1, p2);
                 *reinterpret_cast<uint2*>(halo + hdst[i]) = p1;
                 *reinterpret_cast<uint2*>(halo + hdst[i] + 32) = p2;
             }
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
                 lane_hw(i, ih, iw);
                 const int h = h0 + ih, w_ = w0 + iw;
                 if (nok && h < p.H && w_ < p.W && (!(p.dbg & 1) || acc[mt][nt][r] == 1.2345f)) {
-                    const float v = acc[mt][nt][r] * DESCALE + bv;
+                    const float v = acc[mt][nt][r] * descale + bv;
                     p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w_) * p.N + n] = v;
                     ssum += v;
                     ssq += v * v;
@@ -298,6 +300,8 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3b[];
     unsigned char* halo = smem_f3b;                    // [HF*HH8*HWD slots][PST]
 
+    const float sa = p.act_scale != 0.f ? p.act_scale : SA;            // (uniform: scalar registers)
+    const float descale = 1.0f / (sa * SW);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, hh = lane >> 5;
     const int ntn = p.Npad / BN;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
 #pragma unroll
         for (int i = 0; i < HLOADS; ++i) {
             uint2 p1, p2;
-            split2(hreg[i] * SA, p1, p2);
+            split2(hreg[i] * sa, p1, p2);
             hpk[i] = uint4{p1.x, p1.y, p2.x, p2.y};
         }
     };
@@ -517,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
                 float* base = p.out + ((((long long)b * p.F + f) * p.H + h) * p.W + w0) * p.N + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[mt][nt][r] * DESCALE + bv;
+                    const float v = acc[mt][nt][r] * descale + bv;
                     base[poff[r]] = v;
                     ssum += v;
                     ssq += v * v;

@@ -225,7 +225,7 @@ namespace g3 {
 constexpr int BM = 128, BK = 32;
 constexpr int RS = 144;                     // LDS bytes per A row (2 planes x 64 B + 16 pad)
 constexpr int WROW = 128;                   // packed weight bytes per output channel per iteration
-constexpr float SA = 16.0f, SW = 4096.0f, DESCALE = 1.0f / 65536.0f;
+constexpr float SA = 16.0f, SW = 4096.0f;
 typedef _Float16 f16x2_g __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
     unsigned r;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint2 p1, p2;
-            split2(ra[i] * SA, p1, p2);
+            split2(ra[i] * p.act_scale, p1, p2);
             unsigned char* dst = As + (arow + 32 * i) * RS + acol * 2;
             *reinterpret_cast<uint2*>(dst) = p1;
             *reinterpret_cast<uint2*>(dst + 64) = p2;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
                     }
                     const int n = n0 + wn * (BN / 2) + nt * 32 + (l31 & ~3);
                     if (m >= p.M || n >= p.N) continue;
-                    f32x4 v = f32x4{x[0], x[1], x[2], x[3]} * DESCALE;
+                    f32x4 v = f32x4{x[0], x[1], x[2], x[3]} * p.descale;
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.N + n);
                     if (p.gn_raw) {
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (ncol[nt] >= p.N) continue;
-                float v = acc[mt][nt][r] * DESCALE + bv[nt];
+                float v = acc[mt][nt][r] * p.descale + bv[nt];
                 if (rrow) v += rrow[ncol[nt]];
                 if (grow) {
                     const float y = (grow[ncol[nt]] - gmu[nt]) * gga[nt] + gbe[nt];
@@ -520,12 +520,12 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
 // second half of a split-K launch: out = (sum of the slices in index order) * 2^-16 + bias (+ residual), [M][N] layout
 __global__ __launch_bounds__(256) void igemm3_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out, long long MN,
-                                                            int N, int nsl) {
+                                                            int N, int nsl, float descale) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= MN) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
     for (int s = 1; s < nsl; ++s) v += *reinterpret_cast<const f32x4*>(part + (long long)s * MN + i);
-    v *= g3::DESCALE;
+    v *= descale;
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int)(i % N));
     if (resid) v += *reinterpret_cast<const f32x4*>(resid + i);
     *reinterpret_cast<f32x4*>(out + i) = v;
@@ -534,8 +534,11 @@ __global__ __launch_bounds__(256) void igemm3_reduce_kernel(const float* __restr
 // sized for the larger (bf16x6) layout; the f16x3 layout uses 128 of the 192 bytes per (iteration, n)
 size_t igemm6_packed_bytes(int Npad, int K, int ntaps) { return (size_t)ntaps * igemm_kchunks(K) * Npad * 192; }
 
-int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
+int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     using namespace g6;
+    IgemmParams p = p_in;
+    if (p.act_scale == 0.f) p.act_scale = g3::SA;                    // f16x3 kernels: activation scale and its inverse x 2^-12
+    p.descale = 1.0f / (p.act_scale * g3::SW);
     DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "igemm6: channel counts must be multiples of 4");
     DPC_REQUIRE(p.ntaps >= 1 && p.ntaps <= 32, "igemm6: 1..32 taps");
     DPC_REQUIRE(!(p.ln_stats && (p.ntaps != 1 || p.C1 != 0)), "igemm6: LayerNorm prologue needs a 1-tap single-source op");
@@ -583,7 +586,7 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s) {
             DPC_LAUNCH_CHECK();
             const long long MN = p.M * p.N;
             hipLaunchKernelGGL(igemm3_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, scratch, p.bias, p.resid,
-                               p.out, MN, p.N, nsl);
+                               p.out, MN, p.N, nsl, p.descale);
             DPC_LAUNCH_CHECK();
             return DPC_OK;
         }

@@ -330,4 +330,250 @@ int launch_groupnorm_silu(const float* x, float* out, const float* resid, const 
     return DPC_OK;
 }
 
+
+// ------------------------------------------------------------------ GroupNorm statistics only / GroupNorm+SiLU backward
+// (the jellyfish guidance surrogates: forward keeps the raw conv output + statistics on the tape, the backward pass
+//  recomputes the activation; diffusion_2d_jellyfish.py:122-148 Block / ResnetBlock)
+int launch_gn_stats(const float* x, float* stats, int B, long long R, int C, int groups, void* ws, hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0, "groupnorm: C/4 must divide 256");
+    DPC_REQUIRE(groups >= 1 && C % groups == 0 && groups <= 1024, "groupnorm: groups must divide C");
+    if (B == 0 || R == 0) return DPC_OK;
+    const int nchunk = gn_chunks(R, C);
+    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * R * C, s);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, part, R, C, nchunk);
+    DPC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s, part, stats, R, C, groups, nchunk, B);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// y = silu(z) (+ resid), z = (xhat * gamma + beta) * (scale + 1) + shift, xhat = (x - mean_g) * rstd_g.  Given dy:
+//   dz = dy * silu'(z);  per (sample, channel): A = sum_r dz, Bs = sum_r dz * xhat     (pass 1, fp64 partials per row chunk)
+//   dshift = A, dscale = gamma * Bs + beta * A;  with dxhat = dz * (scale + 1) * gamma and the group means
+//   M1 = mean_g(dxhat), M2 = mean_g(dxhat * xhat):  dx = rstd_g * (dxhat - M1 - xhat * M2)                    (pass 2)
+__device__ __forceinline__ float silu_grad(float z) {
+    const float sg = 1.0f / (1.0f + expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                                            double* __restrict__ part, long long R, int C, int groups, int nchunk) {
+    __shared__ double red[256][8];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / groups, tpr = C >> 2, rpp = 256 / tpr;
+    const int c4 = tid % tpr, rsub = tid / tpr;
+    float mu[4], rs[4], ga[4], be[4], sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c4 * 4 + i, g = c / cpg;
+        mu[i] = stats[2 * (b * groups + g)];
+        rs[i] = stats[2 * (b * groups + g) + 1];
+        ga[i] = gamma[c];
+        be[i] = beta[c];
+        sc[i] = scale_shift ? scale_shift[(long long)b * 2 * C + c] + 1.0f : 1.0f;
+        sh[i] = scale_shift ? scale_shift[(long long)b * 2 * C + C + c] : 0.0f;
+    }
+    const float* xb = x + (long long)b * R * C;
+    const float* db = dy + (long long)b * R * C;
+    const long long rpc = (R + nchunk - 1) / nchunk;
+    const long long r_begin = chunk * rpc, r_end = min(R, r_begin + rpc);
+    double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (long long r = r_begin + rsub; r < r_end; r += rpp) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(db + r * C + c4 * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (v[i] - mu[i]) * rs[i];
+            const float z = (xh * ga[i] + be[i]) * sc[i] + sh[i];
+            const float dz = d[i] * silu_grad(z);
+            a[i] += (double)dz;
+            q[i] += (double)(dz * xh);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[tid][i] = a[i]; red[tid][4 + i] = q[i]; }
+    __syncthreads();
+    if (rsub == 0) {                         // fixed order over the row sub-groups: deterministic
+        double ta[4] = {0, 0, 0, 0}, tq[4] = {0, 0, 0, 0};
+        for (int k = 0; k < rpp; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ta[i] += red[k * tpr + c4][i]; tq[i] += red[k * tpr + c4][4 + i]; }
+        double* dst = part + (((long long)b * nchunk + chunk) * C + c4 * 4) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dst[2 * i] = ta[i]; dst[2 * i + 1] = tq[i]; }
+    }
+}
+
+// one wave per (sample, group): channel sums over the chunks, d(scale, shift), group means -> coef [B][C][4] = (k, M1, M2, 0)
+// with k = (scale + 1) * gamma so that pass 2 is dx = rstd * (dz * k - M1 - xhat * M2)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                                             float* __restrict__ coef, float* __restrict__ dss, long long R, int C,
+                                                             int groups, int nchunk, int B) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= B * groups) return;
+    const int b = wid / groups, g = wid % groups;
+    const int cpg = C / groups;
+    double m1 = 0, m2 = 0;
+    for (int j = lane; j < cpg; j += 64) {
+        const int c = g * cpg + j;
+        double A = 0, Bs = 0;
+        for (int k = 0; k < nchunk; ++k) {
+            const double* src = part + (((long long)b * nchunk + k) * C + c) * 2;
+            A += src[0];
+            Bs += src[1];
+        }
+        const double sc = scale_shift ? (double)scale_shift[(long long)b * 2 * C + c] + 1.0 : 1.0;
+        const double kk = sc * (double)gamma[c];
+        m1 += kk * A;
+        m2 += kk * Bs;
+        if (dss) {
+            dss[(long long)b * 2 * C + c] = (float)((double)gamma[c] * Bs + (double)beta[c] * A);     // d scale
+            dss[(long long)b * 2 * C + C + c] = (float)A;                                             // d shift
+        }
+        coef[((long long)b * C + c) * 4] = (float)kk;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m1 += __shfl_xor(m1, o, 64);
+        m2 += __shfl_xor(m2, o, 64);
+    }
+    const double n = (double)R * cpg;
+    for (int j = lane; j < cpg; j += 64) {
+        const int c = g * cpg + j;
+        coef[((long long)b * C + c) * 4 + 1] = (float)(m1 / n);
+        coef[((long long)b * C + c) * 4 + 2] = (float)(m2 / n);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ scale_shift,
+                                                          const float* __restrict__ coef, float* __restrict__ dx, long long R, int C,
+                                                          int groups, int nblk) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups, tpr = C >> 2, rpp = 256 / tpr;
+    const int c4 = tid % tpr, rsub = tid / tpr;
+    float mu[4], rs[4], ga[4], be[4], sc[4], sh[4], kk[4], m1[4], m2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c4 * 4 + i, g = c / cpg;
+        mu[i] = stats[2 * (b * groups + g)];
+        rs[i] = stats[2 * (b * groups + g) + 1];
+        ga[i] = gamma[c];
+        be[i] = beta[c];
+        sc[i] = scale_shift ? scale_shift[(long long)b * 2 * C + c] + 1.0f : 1.0f;
+        sh[i] = scale_shift ? scale_shift[(long long)b * 2 * C + C + c] : 0.0f;
+        const float* cf = coef + ((long long)b * C + c) * 4;
+        kk[i] = cf[0]; m1[i] = cf[1]; m2[i] = cf[2];
+    }
+    const float* xb = x + (long long)b * R * C;
+    const float* db = dy + (long long)b * R * C;
+    float* ob = dx + (long long)b * R * C;
+    const long long rpb = (R + nblk - 1) / nblk;
+    const long long r_begin = blockIdx.x * rpb, r_end = min(R, r_begin + rpb);
+    for (long long r = r_begin + rsub; r < r_end; r += rpp) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(db + r * C + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (v[i] - mu[i]) * rs[i];
+            const float z = (xh * ga[i] + be[i]) * sc[i] + sh[i];
+            const float dz = d[i] * silu_grad(z);
+            o[i] = rs[i] * (dz * kk[i] - m1[i] - xh * m2[i]);
+        }
+        *reinterpret_cast<f32x4*>(ob + r * C + c4 * 4) = o;
+    }
+}
+
+size_t gn_bwd_workspace_bytes(int B, int C) {
+    return (size_t)B * GN_MAX_CHUNKS * C * 2 * sizeof(double) + (size_t)B * C * 4 * sizeof(float);
+}
+
+int launch_gn_silu_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                       const float* scale_shift, float* dx, float* dss, int B, long long R, int C, int groups, void* ws,
+                       hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0, "groupnorm bwd: C/4 must divide 256");
+    DPC_REQUIRE(groups >= 1 && C % groups == 0 && groups <= 1024, "groupnorm bwd: groups must divide C");
+    if (B == 0 || R == 0) return DPC_OK;
+    const int nchunk = gn_chunks(R, C);
+    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * R * C * 5, s);
+    double* part = reinterpret_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(part + (size_t)B * GN_MAX_CHUNKS * C * 2);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, dy, stats, gamma, beta, scale_shift, part, R, C,
+                       groups, nchunk);
+    DPC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s, part, gamma, beta, scale_shift, coef,
+                       dss, R, C, groups, nchunk, B);
+    DPC_LAUNCH_CHECK();
+    const int rpp = 256 / (C / 4);
+    long long nblk = R / ((long long)rpp * 8);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, dy, stats, gamma, beta, scale_shift, coef, dx, R,
+                       C, groups, (int)nblk);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+// Channel LayerNorm backward (diffusion_2d_jellyfish.py LayerNorm: y = (x - mean) * rstd * g over the channel axis), G lanes per
+// row as ln_stats:  dx = rstd * (dy g - mean_c(dy g) - xhat mean_c(dy g xhat));  accum != 0: dx += (gradient accumulation)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                    const float* __restrict__ g, const float* __restrict__ dy, float* dx,
+                                                    long long rows, int C, int G, int accum) {
+    const int lane = threadIdx.x & 63;
+    const int rows_per_wave = 64 / G;
+    const long long wave_id = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int sub = lane / G, gl = lane % G;
+    const int c4n = C >> 2;
+    for (long long r0 = wave_id * rows_per_wave; r0 < rows; r0 += nwaves * rows_per_wave) {
+        const long long r = r0 + sub;
+        const bool ok = r < rows;
+        const float mean = ok ? stats[2 * r] : 0.f, rstd = ok ? stats[2 * r + 1] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c4 = gl; c4 < c4n; c4 += G) {
+            if (ok) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c4 * 4);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * C + c4 * 4) * *reinterpret_cast<const f32x4*>(g + c4 * 4);
+                const f32x4 xh = (v - mean) * rstd;
+                s1 += (d.x + d.y) + (d.z + d.w);
+                s2 += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 /= (float)C;
+        s2 /= (float)C;
+        for (int c4 = gl; c4 < c4n; c4 += G) {
+            if (ok) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c4 * 4);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * C + c4 * 4) * *reinterpret_cast<const f32x4*>(g + c4 * 4);
+                const f32x4 xh = (v - mean) * rstd;
+                f32x4 o = (d - s1 - xh * s2) * rstd;
+                if (accum) o += *reinterpret_cast<const f32x4*>(dx + r * C + c4 * 4);
+                *reinterpret_cast<f32x4*>(dx + r * C + c4 * 4) = o;
+            }
+        }
+    }
+}
+
+int launch_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, long long rows, int C, int accum,
+                  hipStream_t s) {
+    DPC_REQUIRE(C % 4 == 0, "ln_bwd: C % 4");
+    int G = 1;
+    while (G < 64 && G < C / 4) G <<= 1;
+    const int rows_per_block = 4 * (64 / G);
+    ProfScope prof(PROF_LN, 0, 4.0 * (double)rows * C * 4, s);
+    const long long nb = (rows + rows_per_block - 1) / rows_per_block;
+    const int grid = (int)std::min<long long>(nb, 256 * 16);
+    if (grid == 0) return DPC_OK;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, s, x, stats, g, dy, dx, rows, C, G, accum);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 }  // namespace dpc

@@ -1,0 +1,679 @@
+// Operator-level entry points for the jellyfish guidance surrogates: the two learned 2-D nets that sit INSIDE
+// the design gradient -- `Unet` (boundary updater, diffusion_2d_jellyfish.py:276-403) and `ForceUnet` (:406-481), differentiated
+// by `force_fn` (inference_2d_jellyfish.py:85-114) -- forward AND input-gradient backward on hand-written HIP kernels, so that
+// no torch autograd graph is left in the sampling loop.  The graph itself (which op follows which, what is kept for the
+// backward pass) lives in Python (diffphycon_amd/model/surrogates_hip.py); every tensor-sized operation is one of:
+//   dpc_conv_pack / dpc_conv_run      any 2-D convolution or its input-gradient (the same implicit-GEMM kernel on weights
+//                                     flipped / transposed / sliced by the host at load time), virtual concat, fused channel
+//                                     LayerNorm prologue, residual accumulate, channels-first / parity-scatter outputs
+//   dpc_gn_stats / dpc_gn_apply / dpc_gn_silu_bwd      GroupNorm (+ scale/shift) + SiLU and its backward (norm.hip)
+//   dpc_ln_stats / dpc_ln_apply / dpc_ln_bwd            channel LayerNorm and its backward (norm.hip)
+//   dpc_linear_attention_core / _bwd, dpc_attention_core / dpc_attention_bwd      attention cores (attn.hip, here)
+//   dpc_upsample2x_cl / dpc_downsum2x_cl, dpc_nchw_to_cl / dpc_cl_to_nchw, dpc_mean_rows / dpc_bcast_rows, dpc_small_linear
+// Only [N, C]-sized vectors (time embedding, its MLP gradient) are touched by torch elementwise ops on the host side.
+#include <cmath>
+#include <memory>
+
+#include "common.h"
+#include "unet_common.h"
+
+struct dpc_conv_s {
+    dpc::PackedConv pc;
+    dpc::Modes modes;
+};
+
+namespace dpc {
+
+__device__ __forceinline__ int rowmap_s(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// ------------------------------------------------------------------------------------ linear attention backward
+// forward (LinearAttention.forward, diffusion_2d_jellyfish.py:232-251; the 1/(h w) on v is folded into to_out by the host):
+//   qs = softmax_d(q) * scale, ks = softmax_n(k), ctx[d][e] = sum_n ks[n][d] v[n][e], out[n][e] = sum_d ctx[d][e] qs[n][d]
+// backward, given dout[n][e]:
+//   dctx[d][e] = sum_n qs[n][d] dout[n][e];   dqs[n][d] = sum_e ctx[d][e] dout[n][e]
+//   dq[n][d] = scale * p[n][d] * (dqs[n][d] - sum_d' dqs[n][d'] p[n][d'])          (p = softmax_d(q))
+//   dks[n][d] = sum_e dctx[d][e] v[n][e];  dk[n][d] = ks[n][d] * (dks[n][d] - sum_e dctx[d][e] ctx[d][e])
+//   dv[n][e] = sum_d ks[n][d] dctx[d][e]
+// workspace per (image, head): ctx[1024] | dctx[1024] | kmax[32] | Z[32] | rowdot[32] | pad  = 2176 floats
+constexpr int LAB_WS = 2176;
+
+__global__ __launch_bounds__(256) void linattn_bwd_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                             float* __restrict__ ws, int heads, int N) {
+    __shared__ float s_max[4][32];
+    __shared__ float s_z[4][32];
+    __shared__ float s_acc[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hh = lane >> 5;
+    const long long img = blockIdx.x / heads;
+    const int head = blockIdx.x % heads;
+    const int ld = 3 * heads * 32, HD = heads * 32;
+    const float scale = 0.17677669529663687f;
+    const float* qbase = qkv + img * N * (long long)ld + head * 32 + l31;
+    const float* kbase = qbase + HD;
+    const float* vbase = kbase + HD;
+    const float* dbase = dout + img * N * (long long)HD + head * 32 + l31;
+    int per = (N + 3) / 4;
+    per += per & 1;
+    const int n_begin = wave * per, n_end = min(N, n_begin + per);
+
+    float m = -INFINITY;
+    for (int n = n_begin + hh; n < n_end; n += 2) m = fmaxf(m, kbase[(long long)n * ld]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (hh == 0) s_max[wave][l31] = m;
+    __syncthreads();
+    const float kmax = fmaxf(fmaxf(s_max[0][l31], s_max[1][l31]), fmaxf(s_max[2][l31], s_max[3][l31]));
+
+    f32x16 acc, dacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
+    float z = 0.f;
+    for (int n0 = n_begin; n0 < n_end; n0 += 2) {
+        const int n = n0 + hh;
+        const bool ok = n < n_end;
+        const float a = ok ? expf(kbase[(long long)n * ld] - kmax) : 0.f;
+        const float b = ok ? vbase[(long long)n * ld] : 0.f;
+        z += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        // qs[n][d] for this half-wave's token: softmax over the 32 lanes of the half
+        const float qv = ok ? qbase[(long long)n * ld] : 0.f;
+        float qm = qv;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) qm = fmaxf(qm, __shfl_xor(qm, o, 64));
+        const float qe = expf(qv - qm);
+        float qs = qe;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) qs += __shfl_xor(qs, o, 64);
+        const float qa = ok ? (qe / qs) * scale : 0.f;
+        const float db = ok ? dbase[(long long)n * HD] : 0.f;
+        dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, db, dacc, 0, 0, 0);
+    }
+    z += __shfl_xor(z, 32, 64);
+    if (hh == 0) s_z[wave][l31] = z;
+    float* dst = ws + ((long long)img * heads + head) * LAB_WS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[wave][r][lane] = acc[r];
+    __syncthreads();
+    float cv[16];
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = rowmap_s(r, hh);
+            const float tot = (s_acc[0][r][lane] + s_acc[1][r][lane]) + (s_acc[2][r][lane] + s_acc[3][r][lane]);
+            const float zz = (s_z[0][d] + s_z[1][d]) + (s_z[2][d] + s_z[3][d]);
+            cv[r] = tot / zz;
+            dst[d * 32 + l31] = cv[r];
+        }
+        if (hh == 0) {
+            dst[2048 + l31] = kmax;
+            dst[2080 + l31] = (s_z[0][l31] + s_z[1][l31]) + (s_z[2][l31] + s_z[3][l31]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_acc[wave][r][lane] = dacc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = rowmap_s(r, hh);
+            const float tot = (s_acc[0][r][lane] + s_acc[1][r][lane]) + (s_acc[2][r][lane] + s_acc[3][r][lane]);
+            dst[1024 + d * 32 + l31] = tot;
+            float rd = tot * cv[r];                              // rowdot[d] = sum_e dctx[d][e] ctx[d][e]: reduce over the 32 lanes
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) rd += __shfl_xor(rd, o, 64);
+            if (l31 == 0) dst[2112 + d] = rd;
+        }
+    }
+}
+
+// one wave per (image, 32-token tile, head): dq, dk, dv of the tile
+__global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                             const float* __restrict__ ws, float* __restrict__ dqkv, int heads,
+                                                             int N, long long total_waves, int tiles_per_img) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= total_waves) return;
+    const int head = (int)(wid % heads);
+    const long long rest = wid / heads;
+    const int tile = (int)(rest % tiles_per_img);
+    const long long img = rest / tiles_per_img;
+    const int ld = 3 * heads * 32, HD = heads * 32;
+    const int n = tile * 32 + l31;
+    const bool ok = n < N;
+    const long long row = img * N + (ok ? n : 0);
+    const float scale = 0.17677669529663687f;
+    const float* w = ws + ((long long)img * heads + head) * LAB_WS;
+    const float* ctx = w;
+    const float* dctx = w + 1024;
+    const float* kmaxp = w + 2048;
+    const float* zp = w + 2080;
+    const float* rdp = w + 2112;
+    const float* qrow = qkv + row * ld + head * 32;
+    const float* krow = qrow + HD;
+    const float* vrow = krow + HD;
+    const float* drow = dout + row * HD + head * 32;
+    float* oq = dqkv + row * ld + head * 32;
+
+    // ---- dq: D[d][n] = sum_e ctx[d][e] dout[n][e]    (A: lane = d, k = e parity hh; B: lane = token n)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float a = ctx[l31 * 32 + 2 * i + hh];
+        const float b = ok ? drow[2 * i + hh] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    {
+        f32x4 q[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            q[jj] = *reinterpret_cast<const f32x4*>(qrow + 8 * jj + 4 * hh);
+            m = fmaxf(fmaxf(m, fmaxf(q[jj].x, q[jj].y)), fmaxf(q[jj].z, q[jj].w));
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { q[jj][s] = expf(q[jj][s] - m); sum += q[jj][s]; }
+        sum += __shfl_xor(sum, 32, 64);
+        float dot = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { q[jj][s] /= sum; dot += acc[4 * jj + s] * q[jj][s]; }
+        dot += __shfl_xor(dot, 32, 64);
+        if (ok) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                f32x4 o;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) o[s] = scale * q[jj][s] * (acc[4 * jj + s] - dot);
+                *reinterpret_cast<f32x4*>(oq + 8 * jj + 4 * hh) = o;
+            }
+        }
+    }
+    // ---- dk: D[d][n] = sum_e dctx[d][e] v[n][e];  dk = ks * (D - rowdot[d])
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float a = dctx[l31 * 32 + 2 * i + hh];
+        const float b = ok ? vrow[2 * i + hh] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (ok) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(krow + 8 * jj + 4 * hh);
+            const f32x4 km = *reinterpret_cast<const f32x4*>(kmaxp + 8 * jj + 4 * hh);
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(zp + 8 * jj + 4 * hh);
+            const f32x4 rd = *reinterpret_cast<const f32x4*>(rdp + 8 * jj + 4 * hh);
+            f32x4 o;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o[s] = (expf(kv[s] - km[s]) / zz[s]) * (acc[4 * jj + s] - rd[s]);
+            *reinterpret_cast<f32x4*>(oq + HD + 8 * jj + 4 * hh) = o;
+        }
+    }
+    // ---- dv: D[e][n] = sum_d dctx[d][e] ks[n][d]     (A: lane = e, k = d parity; B: lane = token, ks[n][d])
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = 2 * i + hh;
+        const float a = dctx[d * 32 + l31];
+        const float b = ok ? expf(krow[d] - kmaxp[d]) / zp[d] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (ok) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            *reinterpret_cast<f32x4*>(oq + 2 * HD + 8 * jj + 4 * hh) = f32x4{acc[4 * jj], acc[4 * jj + 1], acc[4 * jj + 2], acc[4 * jj + 3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------ dense attention backward
+// Attention.forward (:266-275): S = (q scale) k^T, P = softmax_j(S), O = P v.  One workgroup per (image, head), L <= 256 tokens,
+// q | k | v | dO of the head in LDS.  Pass Q (thread = query i): row max / sum, t_i = sum_j P_ij dP_ij with dP_ij = dO_i . v_j,
+// dq_i = scale sum_j dS_ij k_j;  pass K (thread = key j): dk_j = scale sum_i dS_ij q_i, dv_j = sum_i P_ij dO_i,
+// dS_ij = P_ij (dP_ij - t_i).
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                      float* __restrict__ dqkv, int heads, int L) {
+    extern __shared__ float s_att[];
+    float* sq = s_att;                 // [L][33]
+    float* sk = sq + L * 33;
+    float* sv = sk + L * 33;
+    float* sd = sv + L * 33;
+    float* sm = sd + L * 33;           // [L] row max
+    float* sl = sm + L;                // [L] row sum
+    float* st = sl + L;                // [L] t_i
+    const long long img = blockIdx.x / heads;
+    const int head = blockIdx.x % heads;
+    const int ld = 3 * heads * 32, HD = heads * 32;
+    const float scale = 0.17677669529663687f;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < L * 32; idx += 256) {
+        const int i = idx >> 5, d = idx & 31;
+        const float* row = qkv + (img * L + i) * (long long)ld + head * 32 + d;
+        sq[i * 33 + d] = row[0] * scale;
+        sk[i * 33 + d] = row[HD];
+        sv[i * 33 + d] = row[2 * HD];
+        sd[i * 33 + d] = dout[(img * L + i) * (long long)HD + head * 32 + d];
+    }
+    __syncthreads();
+    const int i = tid;
+    if (i < L) {
+        float q[32], dO[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { q[d] = sq[i * 33 + d]; dO[d] = sd[i * 33 + d]; }
+        float m = -INFINITY;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s += q[d] * sk[j * 33 + d];
+            m = fmaxf(m, s);
+        }
+        float l = 0.f, t = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += q[d] * sk[j * 33 + d]; dp += dO[d] * sv[j * 33 + d]; }
+            const float e = expf(s - m);
+            l += e;
+            t += e * dp;
+        }
+        t /= l;
+        sm[i] = m; sl[i] = l; st[i] = t;
+        float dq[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dq[d] = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += q[d] * sk[j * 33 + d]; dp += dO[d] * sv[j * 33 + d]; }
+            const float ds = (expf(s - m) / l) * (dp - t);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dq[d] += ds * sk[j * 33 + d];
+        }
+        float* o = dqkv + (img * L + i) * (long long)ld + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = dq[d] * scale;
+    }
+    __syncthreads();
+    const int j = tid;
+    if (j < L) {
+        float k[32], v[32], dk[32], dv[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { k[d] = sk[j * 33 + d]; v[d] = sv[j * 33 + d]; dk[d] = 0.f; dv[d] = 0.f; }
+        for (int ii = 0; ii < L; ++ii) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += sq[ii * 33 + d] * k[d]; dp += sd[ii * 33 + d] * v[d]; }
+            const float pij = expf(s - sm[ii]) / sl[ii];
+            const float ds = pij * (dp - st[ii]);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { dk[d] += ds * sq[ii * 33 + d]; dv[d] += pij * sd[ii * 33 + d]; }
+        }
+        float* o = dqkv + (img * L + j) * (long long)ld + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { o[HD + d] = dk[d]; o[2 * HD + d] = dv[d]; }      // (sq already carries the scale)
+    }
+}
+
+// ------------------------------------------------------------------------------------ small streaming ops
+// y[n][h][w][c] = sum over the 2 x 2 block of x[n][2h+a][2w+b][c]   (backward of the nearest x2 up-sampling)
+__global__ __launch_bounds__(256) void downsum2x_cl_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4,
+                                                          int H, int W, int C4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long r = i / C4;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H);
+        const long long n = r / H;
+        const f32x4* src = reinterpret_cast<const f32x4*>(x) + ((n * 2 * H + 2 * h) * 2 * W + 2 * w) * C4 + c4;
+        reinterpret_cast<f32x4*>(y)[i] = (src[0] + src[C4]) + (src[(long long)2 * W * C4] + src[(long long)2 * W * C4 + C4]);
+    }
+}
+// [N][C][HW] -> [N*HW][Cpad] (zero padded channels) and back ([N*HW][Cpad] -> [N][C][HW], first C channels)
+__global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int C,
+                                                        int Cpad, long long HW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long long p = i / Cpad, n = p / HW, hw = p % HW;
+        y[i] = c < C ? x[(n * C + c) * HW + hw] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void cl_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int C,
+                                                        int Cpad, int csrc, int Ctot, int cdst, float mul, long long HW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        const long long r = i / HW;
+        const int c = (int)(r % C);
+        const long long n = r / C;
+        y[(n * Ctot + cdst + c) * HW + hw] = x[(n * HW + hw) * Cpad + csrc + c] * mul;
+    }
+}
+// y_cl[n][hw][cdst] = a * x[n][csrc][hw] + b     (one channel of a channels-first tensor into one channel of a channels-last one)
+__global__ __launch_bounds__(256) void channel_affine_to_cl_kernel(const float* __restrict__ x, float* __restrict__ y, long long total,
+                                                                  int Ctot, int csrc, int Cpad, int cdst, float a, float b, long long HW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, hw = i % HW;
+        y[i * Cpad + cdst] = a * x[(n * Ctot + csrc) * HW + hw] + b;
+    }
+}
+// out[n] = mean_hw x[n][csrc][hw]      one block per image, fp64 accumulation in a fixed order
+__global__ __launch_bounds__(256) void channel_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int Ctot, int csrc,
+                                                          long long HW) {
+    __shared__ double red[256];
+    const float* src = x + ((long long)blockIdx.x * Ctot + csrc) * HW;
+    double s = 0;
+    for (long long i = threadIdx.x; i < HW; i += 256) s += (double)src[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] / (double)HW);
+}
+// y[n][cdst][hw] = v[n] * mul
+__global__ __launch_bounds__(256) void channel_fill_kernel(float* __restrict__ y, const float* __restrict__ v, long long total, int Ctot,
+                                                          int cdst, float mul, long long HW) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, hw = i % HW;
+        y[(n * Ctot + cdst) * HW + hw] = v[n] * mul;
+    }
+}
+// out[n][c] = mean_r x[n][r][c]   (ForceUnet head, :478-480)      one block per (n, 64-channel slab)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ out, long long R, int C) {
+    __shared__ double red[4][64];
+    const long long n = blockIdx.y;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    double s = 0;
+    if (c < C)
+        for (long long r = part; r < R; r += 4) s += (double)x[(n * R + r) * C + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < C) out[n * C + c] = (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) / (double)R);
+}
+// y[n][r][c] = v[n][c] * mul      (backward of the mean over pixels)
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* __restrict__ v, float* __restrict__ y, long long total4, long long R,
+                                                        int C4, float mul) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long n = i / C4 / R;
+        reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(v)[n * C4 + c4] * mul;
+    }
+}
+// y += x
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long long total4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(y)[i] += reinterpret_cast<const f32x4*>(x)[i];
+}
+
+// out[0] = max(out[0], max |x|)   (bit pattern of a non-negative float orders like an unsigned integer)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ out, long long total4) {
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+static inline unsigned grid_for(long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 256 * 16); }
+
+}  // namespace dpc
+
+using namespace dpc;
+
+extern "C" {
+
+int dpc_conv_pack(const float* w, int N, int K, int kh, int kw, int sh, int sw, int ph, int pw, int tap_begin, int tap_end,
+                  const char* mode, dpc_conv_t* out, dpc_stream_t stream) {
+    DPC_REQUIRE(w && out && N >= 1 && K >= 1 && kh >= 1 && kw >= 1, "conv_pack: bad argument");
+    DPC_REQUIRE(K % 4 == 0, "conv_pack: input channels must be a multiple of 4 (pad on the host)");
+    if (tap_end <= 0) tap_end = kh * kw;
+    const int ntaps = tap_end - tap_begin;
+    DPC_REQUIRE(tap_begin >= 0 && ntaps >= 1 && ntaps <= 32 && tap_end <= kh * kw, "conv_pack: 1..32 taps per pack (split larger kernels)");
+    hipStream_t s = (hipStream_t)stream;
+    auto h = std::make_unique<dpc_conv_s>();
+    h->modes = modes_global();
+    if (mode && mode[0]) {
+        const std::string m(mode);
+        const int v = m == "f32" ? 0 : (m == "x6" ? 1 : (m == "f16x3" ? 2 : -1));
+        DPC_REQUIRE(v >= 0, "conv_pack: unknown arithmetic mode '" + m + "'");
+        h->modes.igemm = v;
+        h->modes.conv = v;
+    }
+    ModeScope scope(h->modes);
+    PackedConv& pc = h->pc;
+    if (tap_begin == 0 && ntaps == kh * kw) {
+        // whole window: the U-Nets' own packer (3 x 3 stride-1 convs in f16x3 mode also get the big-tile halo pack, conv3f3.hip)
+        if (int rc = pack_conv3d(pc, w, N, K, 1, kh, kw, sh, sw, 0, ph, pw, s)) return rc;
+        if (igemm_mode_default() == 2)
+            if (int rc = f16x3_weight_overflow_check("conv_pack")) return rc;
+        *out = h.release();
+        return DPC_OK;
+    }
+    pc.N = N; pc.K = K; pc.Npad = igemm_npad(N); pc.kchunks = igemm_kchunks(K); pc.ntaps = ntaps;
+    pc.sh = sh; pc.sw = sw; pc.halo = false; pc.flat3 = false;
+    int off[32];
+    for (int t = 0; t < ntaps; ++t) {
+        const int tap = tap_begin + t;
+        pc.tdf[t] = 0;
+        pc.tdh[t] = (signed char)(tap / kw - ph);
+        pc.tdw[t] = (signed char)(tap % kw - pw);
+        off[t] = tap;
+    }
+    int rc = pc.wp.alloc((size_t)ntaps * pc.kchunks * pc.Npad * 32 * sizeof(float));
+    if (rc) return rc;
+    const long long taps_all = (long long)kh * kw;
+    if ((rc = launch_pack_weights(w, pc.wp.f(), N, pc.Npad, K, ntaps, (long long)K * taps_all, taps_all, off, s))) return rc;
+    if (igemm_mode_default() != 0) {
+        if ((rc = pc.wp6g.alloc(igemm6_packed_bytes(pc.Npad, K, ntaps)))) return rc;
+        if ((rc = launch_pack_weights_g6(w, pc.wp6g.p, N, pc.Npad, K, ntaps, (long long)K * taps_all, taps_all, off, s))) return rc;
+        if (igemm_mode_default() == 2)
+            if ((rc = f16x3_weight_overflow_check("conv_pack"))) return rc;
+    }
+    *out = h.release();
+    return DPC_OK;
+}
+
+void dpc_conv_free(dpc_conv_t h) { delete h; }
+
+int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
+                 int BF, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
+                 int par_b, float act_scale, dpc_stream_t stream) {
+    DPC_REQUIRE(h && a0 && out, "conv_run: null argument");
+    if (act_scale != 0.f) {
+        int e = 0;
+        DPC_REQUIRE(act_scale > 0.f && std::frexp(act_scale, &e) == 0.5f, "conv_run: act_scale must be a power of two (or 0)");
+    }
+    ModeScope scope(h->modes);
+    return run_conv(h->pc, a0, a1, C0, C1, bias, resid, out, BF, 1, Hi, Wi, Ho, Wo, ln_stats, ln_gamma, out_mode, par_a, par_b,
+                    (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, act_scale);
+}
+
+size_t dpc_gn_workspace_bytes(int B, int C) { return std::max(gn_workspace_bytes(B, C), gn_bwd_workspace_bytes(B, C)) + 256; }
+
+int dpc_gn_stats(const float* x, float* stats, int B, int64_t R, int C, int groups, void* ws, size_t ws_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(x && stats && ws && ws_bytes >= dpc_gn_workspace_bytes(B, C), "gn_stats: bad argument / workspace too small");
+    return launch_gn_stats(x, stats, B, R, C, groups, reinterpret_cast<void*>(align_up((size_t)ws, 256)), (hipStream_t)stream);
+}
+
+int dpc_gn_apply(const float* x, float* out, const float* resid, const float* stats, const float* gamma, const float* beta,
+                 const float* scale_shift, int B, int64_t R, int C, int groups, dpc_stream_t stream) {
+    DPC_REQUIRE(x && out && stats && gamma && beta, "gn_apply: null argument");
+    return launch_gn_apply(x, out, resid, stats, gamma, beta, scale_shift, B, R, C, groups, (hipStream_t)stream);
+}
+
+int dpc_gn_silu_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                    const float* scale_shift, float* dx, float* dss, int B, int64_t R, int C, int groups, void* ws, size_t ws_bytes,
+                    dpc_stream_t stream) {
+    DPC_REQUIRE(x && dy && stats && gamma && beta && dx && ws && ws_bytes >= dpc_gn_workspace_bytes(B, C),
+                "gn_silu_bwd: bad argument / workspace too small");
+    return launch_gn_silu_bwd(x, dy, stats, gamma, beta, scale_shift, dx, dss, B, R, C, groups,
+                              reinterpret_cast<void*>(align_up((size_t)ws, 256)), (hipStream_t)stream);
+}
+
+int dpc_ln_stats(const float* x, float* stats, int64_t rows, int C, dpc_stream_t stream) {
+    DPC_REQUIRE(x && stats, "ln_stats: null argument");
+    return launch_ln_stats(x, stats, rows, C, (hipStream_t)stream);
+}
+
+int dpc_ln_apply(const float* x, const float* stats, const float* g, const float* resid, float* out, int64_t rows, int C,
+                 dpc_stream_t stream) {
+    DPC_REQUIRE(x && stats && g && out, "ln_apply: null argument");
+    return launch_ln_apply(x, stats, g, resid, out, rows, C, (hipStream_t)stream);
+}
+
+int dpc_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, int64_t rows, int C, int accumulate,
+               dpc_stream_t stream) {
+    DPC_REQUIRE(x && stats && g && dy && dx, "ln_bwd: null argument");
+    return launch_ln_bwd(x, stats, g, dy, dx, rows, C, accumulate, (hipStream_t)stream);
+}
+
+size_t dpc_linear_attention_bwd_workspace_bytes(int64_t images, int heads) { return (size_t)images * heads * LAB_WS * sizeof(float) + 256; }
+
+int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int N, void* ws,
+                             size_t ws_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(qkv && dout && dqkv && ws && ws_bytes >= dpc_linear_attention_bwd_workspace_bytes(images, heads),
+                "linear_attention_bwd: bad argument / workspace too small");
+    if (images == 0) return DPC_OK;
+    DPC_REQUIRE(images * heads < (1ll << 31), "linear_attention_bwd: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    float* w = reinterpret_cast<float*>(align_up((size_t)ws, 256));
+    const double rows_ = (double)images * N;
+    ProfScope prof(PROF_LINATTN, 12.0 * rows_ * 32 * 32 * heads, 4.0 * rows_ * heads * 32 * 14, s);
+    hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3((unsigned)(images * heads)), dim3(256), 0, s, qkv, dout, w, heads, N);
+    DPC_LAUNCH_CHECK();
+    const int tiles = (N + 31) / 32;
+    const long long total = images * tiles * heads;
+    hipLaunchKernelGGL(linattn_bwd_tok_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, dout, w, dqkv, heads, N, total,
+                       tiles);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int L, dpc_stream_t stream) {
+    DPC_REQUIRE(qkv && dout && dqkv && L >= 1 && L <= 256, "attention_bwd: bad argument (1 <= L <= 256 tokens)");
+    if (images == 0) return DPC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = ((size_t)4 * L * 33 + 3 * L) * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        DPC_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 256 * 33 + 3 * 256) * 4));
+        once = true;
+    }
+    ProfScope prof(PROF_ATTN, 10.0 * (double)images * heads * L * L * 32, 0, s);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(images * heads)), dim3(256), lds, s, qkv, dout, dqkv, heads, L);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_upsample2x_cl(const float* x, float* y, int BF, int H, int W, int C, dpc_stream_t stream) {
+    DPC_REQUIRE(x && y && C % 4 == 0, "upsample2x_cl: bad argument");
+    return launch_upsample2x_cl(x, y, BF, H, W, C, (hipStream_t)stream);
+}
+
+int dpc_downsum2x_cl(const float* x, float* y, int BF, int H, int W, int C, dpc_stream_t stream) {
+    DPC_REQUIRE(x && y && C % 4 == 0, "downsum2x_cl: bad argument");
+    const long long total4 = (long long)BF * H * W * (C / 4);
+    if (total4 == 0) return DPC_OK;
+    hipLaunchKernelGGL(downsum2x_cl_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, total4, H, W, C / 4);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_nchw_to_cl(const float* x, float* y, int64_t N, int C, int Cpad, int64_t HW, dpc_stream_t stream) {
+    DPC_REQUIRE(x && y && Cpad >= C, "nchw_to_cl: bad argument");
+    const long long total = N * HW * Cpad;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(nchw_to_cl_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, C, Cpad, HW);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_cl_to_nchw(const float* x, float* y, int64_t N, int C, int Cpad, int csrc, int Ctot, int cdst, float mul, int64_t HW,
+                   dpc_stream_t stream) {
+    DPC_REQUIRE(x && y && csrc >= 0 && cdst >= 0 && csrc + C <= Cpad && cdst + C <= Ctot, "cl_to_nchw: bad argument");
+    const long long total = N * HW * C;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(cl_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, C, Cpad, csrc, Ctot, cdst,
+                       mul, HW);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_channel_affine_to_cl(const float* x, float* y, int64_t N, int Ctot, int csrc, int Cpad, int cdst, float a, float b, int64_t HW,
+                             dpc_stream_t stream) {
+    DPC_REQUIRE(x && y && csrc >= 0 && csrc < Ctot && cdst >= 0 && cdst < Cpad, "channel_affine_to_cl: bad argument");
+    const long long total = N * HW;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(channel_affine_to_cl_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, Ctot, csrc, Cpad,
+                       cdst, a, b, HW);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_channel_mean(const float* x, float* out, int64_t N, int Ctot, int csrc, int64_t HW, dpc_stream_t stream) {
+    DPC_REQUIRE(x && out && csrc >= 0 && csrc < Ctot, "channel_mean: bad argument");
+    if (N == 0) return DPC_OK;
+    hipLaunchKernelGGL(channel_mean_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, x, out, Ctot, csrc, HW);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_channel_fill(float* y, const float* v, int64_t N, int Ctot, int cdst, float mul, int64_t HW, dpc_stream_t stream) {
+    DPC_REQUIRE(y && v && cdst >= 0 && cdst < Ctot, "channel_fill: bad argument");
+    const long long total = N * HW;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(channel_fill_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, v, total, Ctot, cdst, mul, HW);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_mean_rows(const float* x, float* out, int64_t N, int64_t R, int C, dpc_stream_t stream) {
+    DPC_REQUIRE(x && out, "mean_rows: null argument");
+    if (N == 0) return DPC_OK;
+    hipLaunchKernelGGL(mean_rows_kernel, dim3((C + 63) / 64, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, out, R, C);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_bcast_rows(const float* v, float* y, int64_t N, int64_t R, int C, float mul, dpc_stream_t stream) {
+    DPC_REQUIRE(v && y && C % 4 == 0, "bcast_rows: bad argument");
+    const long long total4 = N * R * (C / 4);
+    if (total4 == 0) return DPC_OK;
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, v, y, total4, R, C / 4, mul);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_add_inplace(float* y, const float* x, int64_t n, dpc_stream_t stream) {
+    DPC_REQUIRE(y && x && n % 4 == 0, "add_inplace: bad argument");
+    if (n == 0) return DPC_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_absmax(const float* x, int64_t n, float* out, dpc_stream_t stream) {
+    DPC_REQUIRE(x && out && n % 4 == 0, "absmax: bad argument");
+    if (n == 0) return DPC_OK;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<unsigned*>(out), n / 4);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_small_linear(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int in_act, int out_act,
+                     dpc_stream_t stream) {
+    DPC_REQUIRE(in && W && out, "small_linear: null argument");
+    return launch_small_linear(in, W, bias, out, B, K, N, in_act, out_act, (hipStream_t)stream);
+}
+
+}  // extern "C"

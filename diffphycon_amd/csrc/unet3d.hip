@@ -179,7 +179,7 @@ int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
              const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part,
-             const float* in_coef, const float* gn_raw, const float* gn_coef) {
+             const float* in_coef, const float* gn_raw, const float* gn_coef, float act_scale) {
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
     DPC_REQUIRE(!gn_raw || (!pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && gn_coef),
                 "conv: the fused GroupNorm residual needs the f16x3 implicit GEMM");
@@ -209,6 +209,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         Conv3hParams q{};
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = reinterpret_cast<const float*>(pc.wp3.p); q.bias = bias; q.out = out;
         q.B = 1; q.F = BF; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = (pc.K + 15) / 16; q.kd = 1;
+        q.act_scale = act_scale;
         if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, nullptr, 0, s)) return r;
         return launch_conv3f3(q, s);
     }
@@ -222,6 +223,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
     for (int i = 0; i < 32; ++i) { p.tdf[i] = pc.tdf[i]; p.tdh[i] = pc.tdh[i]; p.tdw[i] = pc.tdw[i]; }
     p.M = (long long)BF * Ho * Wo;
     p.gn_raw = gn_raw; p.gn_coef = gn_coef; p.gn_rows = (long long)F * Ho * Wo;
+    p.act_scale = act_scale;
     if (pc.wp6g.p) {
         if (igemm_mode_default() == 2 && !ln_stats)      // (a LayerNorm prologue normalises the operand before the split)
             if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, nullptr, 0, s)) return r;

@@ -2,8 +2,8 @@
 (/root/reference/diffusion/diffusion_2d_jellyfish.py:529-1006) driving libdpc.
 
 Per step: joint Unet3D forward (7 -> 4 channels) + theta Unet3D forward (7 -> 1) on libdpc, ONE posterior kernel
-(dpc_ddpm_update_jelly), the design gradient through the two learned 2-D surrogates (autograd, PyTorch-ROCm; SURVEY.md
-8a-C2), ONE guidance kernel (dpc_jelly_apply_guidance), the boundary updater forward and the conditioning writes.
+(dpc_ddpm_update_jelly), the design gradient through the two learned 2-D surrogates (model/surrogates_hip.py: forward and
+backward on libdpc; or any callable, e.g. `force_fn` below on the torch modules + autograd), ONE guidance kernel (dpc_jelly_apply_guidance), the boundary updater forward and the conditioning writes.
 `Unet` / `ForceUnet` (the surrogates) and `force_fn` / `reg_theta` keep the reference's names."""
 import ctypes as C
 import math
@@ -161,6 +161,8 @@ class GaussianDiffusion(nn.Module):
         return eps_j, self.model_thetas(x_w, t_b)
 
     def _design(self, design_fn, x0, bd_0_expand):
+        if getattr(design_fn, "analytic", False):          # HipDesignGradient: explicit backward pass, no autograd graph
+            return design_fn(x0, bd_0_expand)
         with torch.enable_grad():
             return design_fn(x0.clone().detach().requires_grad_(), bd_0_expand)
 

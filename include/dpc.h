@@ -192,6 +192,71 @@ int dpc_attention_core(const float* qkv, float* out, int heads, int L, int64_t n
 int dpc_linear_attention_core(const float* qkv, float* out, int heads, int64_t images, int N, void* ws,
                               size_t ws_bytes, dpc_stream_t stream);
 
+/* ------------------------------------------------------------------ operator set of the jellyfish guidance surrogates
+ * The two learned 2-D nets inside the design gradient -- diffusion/diffusion_2d_jellyfish.py `Unet` :276-403 (boundary
+ * updater) and `ForceUnet` :406-481, differentiated by inference_2d_jellyfish.py force_fn :85-114 -- run forward AND
+ * input-gradient backward on these entry points (graph in diffphycon_amd/model/surrogates_hip.py); all tensors are
+ * channels-last fp32 [images * H * W, C] unless stated.
+ *
+ * dpc_conv_pack: weight [N][K][kh][kw] (reference Conv2d layout; the host passes flipped / transposed / sliced /
+ * weight-standardised :107-120 copies for the backward-data and special cases), taps [tap_begin, tap_end) of the kernel
+ * window (<= 32 per pack; tap_end <= 0 means all), K % 4 == 0; mode "" (process default) | "f32" | "x6" | "f16x3".
+ * dpc_conv_run: out = conv(cat(a0[C0], a1[C1])) + bias + resid; ln_stats/ln_gamma: channel-LayerNorm prologue (:195-210)
+ * for 1-tap ops; out_mode 0 [rows][N], 1 channels-first [images][N][Ho*Wo], 2 parity scatter into [images][2Ho][2Wo][N].
+ * act_scale (f16x3 mode; 0 = the default 2^4): power-of-two scale applied to the input before the fp16 operand split and
+ * undone in the epilogue -- the backward pass uses it to place gradients of any magnitude inside the fp16 window. */
+typedef struct dpc_conv_s* dpc_conv_t;
+int dpc_conv_pack(const float* w, int N, int K, int kh, int kw, int sh, int sw, int ph, int pw, int tap_begin, int tap_end,
+                  const char* mode, dpc_conv_t* out, dpc_stream_t stream);
+void dpc_conv_free(dpc_conv_t h);
+int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
+                 int images, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
+                 int par_b, float act_scale, dpc_stream_t stream);
+/* GroupNorm (:140-157 Block): stats [B][groups][2] = (mean, rstd); apply: out = SiLU(GN(x) * (scale + 1) + shift) (+ resid),
+ * scale_shift [B][2C] or NULL; backward: dx and (dss != NULL) d scale_shift [B][2C] given dy. */
+size_t dpc_gn_workspace_bytes(int B, int C);
+int dpc_gn_stats(const float* x, float* stats, int B, int64_t rows_per_sample, int C, int groups, void* ws, size_t ws_bytes,
+                 dpc_stream_t stream);
+int dpc_gn_apply(const float* x, float* out, const float* resid, const float* stats, const float* gamma, const float* beta,
+                 const float* scale_shift, int B, int64_t rows_per_sample, int C, int groups, dpc_stream_t stream);
+int dpc_gn_silu_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                    const float* scale_shift, float* dx, float* dss, int B, int64_t rows_per_sample, int C, int groups, void* ws,
+                    size_t ws_bytes, dpc_stream_t stream);
+/* channel LayerNorm (:195-204): stats [rows][2]; apply: out = resid + (x - mean) * rstd * g; backward: dx (accumulate != 0: +=). */
+int dpc_ln_stats(const float* x, float* stats, int64_t rows, int C, dpc_stream_t stream);
+int dpc_ln_apply(const float* x, const float* stats, const float* g, const float* resid, float* out, int64_t rows, int C,
+                 dpc_stream_t stream);
+int dpc_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, int64_t rows, int C, int accumulate,
+               dpc_stream_t stream);
+/* backward of dpc_linear_attention_core (LinearAttention :232-251 without the v / (h w), which the host folds into to_out)
+ * and of dpc_attention_core for whole-image sequences (Attention :266-275, L <= 256 tokens): dqkv [rows][3*heads*32]. */
+size_t dpc_linear_attention_bwd_workspace_bytes(int64_t images, int heads);
+int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int N, void* ws,
+                             size_t ws_bytes, dpc_stream_t stream);
+int dpc_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int L, dpc_stream_t stream);
+/* nearest x2 up-sampling [images][H][W][C] -> [images][2H][2W][C] (Upsample :89-93) and its backward (2 x 2 block sums) */
+int dpc_upsample2x_cl(const float* x, float* y, int images, int H, int W, int C, dpc_stream_t stream);
+int dpc_downsum2x_cl(const float* dy, float* dx, int images, int H, int W, int C, dpc_stream_t stream);
+/* layout glue at the boundary of the surrogates: channels-first [N][C][HW] <-> channels-last [N*HW][Cpad] */
+int dpc_nchw_to_cl(const float* x, float* y, int64_t N, int C, int Cpad, int64_t HW, dpc_stream_t stream);
+int dpc_cl_to_nchw(const float* x, float* y, int64_t N, int C, int Cpad, int csrc, int Ctot, int cdst, float mul, int64_t HW,
+                   dpc_stream_t stream);
+/* y_cl[n][hw][cdst] = a * x[n][csrc][hw] + b (force_fn :96-101: un-normalised pressure into the ForceUnet input) */
+int dpc_channel_affine_to_cl(const float* x, float* y, int64_t N, int Ctot, int csrc, int Cpad, int cdst, float a, float b,
+                             int64_t HW, dpc_stream_t stream);
+/* out[n] = mean_hw x[n][csrc][hw] (force_fn :94 theta) and its backward y[n][cdst][hw] = v[n] * mul */
+int dpc_channel_mean(const float* x, float* out, int64_t N, int Ctot, int csrc, int64_t HW, dpc_stream_t stream);
+int dpc_channel_fill(float* y, const float* v, int64_t N, int Ctot, int cdst, float mul, int64_t HW, dpc_stream_t stream);
+/* out[n][c] = mean_r x[n][r][c] (ForceUnet head :478-480) and its backward y[n][r][c] = v[n][c] * mul;  y += x */
+int dpc_mean_rows(const float* x, float* out, int64_t N, int64_t R, int C, dpc_stream_t stream);
+int dpc_bcast_rows(const float* v, float* y, int64_t N, int64_t R, int C, float mul, dpc_stream_t stream);
+int dpc_add_inplace(float* y, const float* x, int64_t n, dpc_stream_t stream);
+/* out[0] = max(out[0], max_i |x[i]|) (the caller zeroes out; range calibration of the f16x3 backward pass) */
+int dpc_absmax(const float* x, int64_t n, float* out, dpc_stream_t stream);
+/* out[b][n] = out_act(bias[n] + sum_k in_act(in[b][k]) W[n][k]), act 0 none | 1 SiLU | 2 GELU (time MLPs :300-305, :128-131) */
+int dpc_small_linear(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int in_act, int out_act,
+                     dpc_stream_t stream);
+
 /* ------------------------------------------------------------------ Burgers finite-difference solver
  * Replaces dataset/apps/generate_burgers.py:207-299 burgers_numeric_solve_free (fp32, explicit Euler).
  * u0 [N,nx], f [N,num_t,nx] -> traj [N,num_t+1,nx]. */

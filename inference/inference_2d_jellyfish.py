@@ -1,6 +1,7 @@
 """2-D jellyfish control inference with the reference's entry surface (inference/inference_2d_jellyfish.py, DDPM
 method): same flags for the sampler, `reg_theta / force_fn / load_model / InferencePipeline.run_model_DDPM` structure,
-running the two space-time U-Nets on libdpc and the two 2-D surrogates on PyTorch-ROCm autograd.
+running the two space-time U-Nets and (forward + backward) the two 2-D surrogates on libdpc; DPC_JELLY_SURROGATES=torch
+selects the torch-autograd surrogates for A/B runs.
 
 Not carried over: the SAC / MPC baselines and the surrogate-simulator evaluation pipeline (`sim_ppl_2d`), which are
 baselines/ evaluation code outside the sampling hot path.  Without `--synthetic True` the test split is read
@@ -67,9 +68,15 @@ def load_model(args):
     diffusion = _ddpm([diffusion_joint.model, diffusion_thetas.model], args, eval_2ddpm=True, w_prob_exp=args.w_prob_exp,
                       use_guidance_in_model_predictions=args.use_guidance_in_model_predictions)
 
-    def design_fn(x, bd_0):
-        grad_state, grad_theta = force_fn(x, bd_0, force_model, bd_updater, args)
-        return torch.cat([grad_state, grad_theta.unsqueeze(2)], dim=2)
+    if os.environ.get("DPC_JELLY_SURROGATES", "hip") == "hip":
+        # forward + input-gradient backward of both surrogates on libdpc (csrc/surr.hip): no autograd graph in the loop
+        from diffphycon_amd.model.surrogates_hip import HipDesignGradient
+        design_fn = HipDesignGradient(force_model, bd_updater, args)
+        bd_updater = design_fn.unet
+    else:                                   # A/B: the torch modules + autograd (what r01 shipped)
+        def design_fn(x, bd_0):
+            grad_state, grad_theta = force_fn(x, bd_0, force_model, bd_updater, args)
+            return torch.cat([grad_state, grad_theta.unsqueeze(2)], dim=2)
 
     return force_model, diffusion, bd_updater, design_fn
 

@@ -48,11 +48,14 @@ def env(dev):
                                     sampling_timesteps=T, loss_type="l2", objective="pred_noise", eval_2ddpm=True,
                                     device=dev, **kw), guid
 
-    return g, bd, design_fn, make
+    from diffphycon_amd.model.surrogates_hip import HipDesignGradient
+    args.image_size = 16
+    hip = HipDesignGradient(fm, bd, args)
+    return g, bd, design_fn, make, hip
 
 
 def test_design_gradient_on_gpu(env, dev):
-    g, bd, design_fn, make = env
+    g, bd, design_fn, make, hip = env
     bd0e = torch.from_numpy(g["bd_0"]).to(dev).unsqueeze(1).expand(-1, FR, -1, -1, -1)
     got = design_fn(torch.from_numpy(g["grad:x"]).to(dev).clone(), bd0e).cpu()
     ref = torch.from_numpy(g["grad:g"])
@@ -64,7 +67,7 @@ def test_teacher_forced_posterior_and_guidance_kernels(env, tag, dev):
     """The two HIP kernels on the reference's recorded inputs, with the reference-side gradient injected (isolates the
     kernels from the surrogate backward)."""
     from oracle import sampler_jelly as S
-    g, bd, design_fn, make = env
+    g, bd, design_fn, make, hip = env
     gd, guid = make(tag)
     sched = S.make_schedule(T, "sigmoid")
     steps = torch.from_numpy(g[f"{tag}:noise_steps"])
@@ -87,7 +90,7 @@ def test_teacher_forced_posterior_and_guidance_kernels(env, tag, dev):
 
 @pytest.mark.parametrize("tag", ["alpha", "std"])
 def test_free_running_chain_vs_reference(env, tag, dev):
-    g, bd, design_fn, make = env
+    g, bd, design_fn, make, hip = env
     gd, guid = make(tag)
     draws = [torch.from_numpy(g[f"{tag}:noise_init_{k}"]) for k in ("state", "bd", "theta")] + \
         list(torch.from_numpy(g[f"{tag}:noise_steps"]))
@@ -99,9 +102,24 @@ def test_free_running_chain_vs_reference(env, tag, dev):
     assert (theta.cpu() - torch.from_numpy(g[f"{tag}:theta"])).abs().max() < 5e-3
 
 
+@pytest.mark.parametrize("tag", ["alpha", "std"])
+def test_free_running_chain_with_the_hip_surrogates(env, tag, dev):
+    """Same chain with the design gradient AND the boundary updater on libdpc (no torch surrogate in the loop)."""
+    g, bd, design_fn, make, hip = env
+    gd, guid = make(tag)
+    draws = [torch.from_numpy(g[f"{tag}:noise_init_{k}"]) for k in ("state", "bd", "theta")] + \
+        list(torch.from_numpy(g[f"{tag}:noise_steps"]))
+    it = iter(draws)
+    gd.sample_noise = lambda shape, device: next(it).to(device).clone()
+    states, theta = gd.sample(design_fn=hip, design_guidance=guid, cond=[torch.from_numpy(g["state_0"]),
+                              torch.from_numpy(g["bd_0"])], thetas_0=torch.from_numpy(g["thetas_0"]), bd_updater=hip.unet)
+    assert (states.cpu() - torch.from_numpy(g[f"{tag}:states"])).abs().max() < 5e-3
+    assert (theta.cpu() - torch.from_numpy(g[f"{tag}:theta"])).abs().max() < 5e-3
+
+
 def test_ddim_and_unconditional_paths_run(env, dev):
     from diffphycon_amd.diffusion import diffusion_2d_jellyfish as DJ
-    g, bd, design_fn, make = env
+    g, bd, design_fn, make, hip = env
     gd, guid = make("alpha")
     gd2 = DJ.GaussianDiffusion([gd.model_states, gd.model_thetas], image_size=16, frames=FR, cond_steps=1, timesteps=T,
                                sampling_timesteps=5, ddim_sampling_eta=1.0, loss_type="l2", eval_2ddpm=True, device=dev)

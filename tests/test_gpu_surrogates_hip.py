@@ -1,0 +1,300 @@
+"""GPU parity of the jellyfish guidance surrogates on libdpc (diffphycon_amd/model/surrogates_hip.py, csrc/surr.hip): the
+operator set against fp64 torch autograd, the two nets against the reference's recorded forward outputs
+(tests/golden/jelly_surrogates.npz) and the design gradient against the reference's recorded gradient
+(tests/golden/jelly_sampler.npz `grad:g`, produced by the reference's own modules + torch.autograd on CPU).
+
+Tolerances: operators 2e-5 relative to the tensor's max (fp32 kernels vs an fp64 reference), design gradient 1e-4 relative
+(SURVEY.md 8f-2's bar)."""
+import argparse
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda:0")
+
+
+def rel(got, ref):
+    return ((got.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item()
+
+
+def cl(x):
+    """[n, C, H, W] -> channels-last rows [n*H*W, C]"""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous().float()
+
+
+def uncl(x, n, H, W):
+    return x.reshape(n, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("mode", ["x6", "f32"])
+def test_conv_run_forward_and_data_gradient(dev, mode):
+    """3x3 'same', two-source concat, residual; its backward-data conv on flipped / transposed weights; 7x7 in two tap packs;
+    stride-2 2x2 (pixel-unshuffle + 1x1) and its parity-scatter backward; channels-first epilogue."""
+    from diffphycon_amd.model import surrogates_hip as SH
+    torch.manual_seed(0)
+    n, H, W = 3, 12, 20
+    x0 = torch.randn(n, 8, H, W, device=dev, dtype=torch.float64)
+    x1 = torch.randn(n, 12, H, W, device=dev, dtype=torch.float64)
+    w = torch.randn(24, 20, 3, 3, device=dev, dtype=torch.float64) * 0.2
+    b = torch.randn(24, device=dev, dtype=torch.float64)
+    r = torch.randn(n, 24, H, W, device=dev, dtype=torch.float64)
+    xin = torch.cat((x0, x1), 1).requires_grad_()
+    ref = F.conv2d(xin, w, b, padding=1) + r
+    got = SH._Conv(w, mode=mode)(cl(x0), n, H, W, a1=cl(x1), bias=b.float(), resid=cl(r))
+    assert rel(uncl(got, n, H, W), ref) < 2e-6
+    dy = torch.randn_like(ref)
+    dref, = torch.autograd.grad(ref, xin, dy)
+    wt = SH._flipT(w.float())
+    d0 = SH._Conv(wt[:8], mode=mode)(cl(dy), n, H, W)
+    d1 = SH._Conv(wt[8:], mode=mode)(cl(dy), n, H, W)
+    assert rel(uncl(d0, n, H, W), dref[:, :8]) < 2e-6 and rel(uncl(d1, n, H, W), dref[:, 8:]) < 2e-6
+    # 7x7 (49 taps) as 32 + 17
+    x4 = torch.randn(n, 4, H, W, device=dev, dtype=torch.float64, requires_grad=True)
+    w7 = torch.randn(16, 4, 7, 7, device=dev, dtype=torch.float64) * 0.1
+    ref7 = F.conv2d(x4, w7, b[:16], padding=3)
+    y = SH._Conv(w7, taps=(0, 32), mode=mode)(cl(x4.detach()), n, H, W, bias=b[:16].float())
+    SH._Conv(w7, taps=(32, 49), mode=mode)(cl(x4.detach()), n, H, W, resid=y, out=y)
+    assert rel(uncl(y, n, H, W), ref7) < 2e-6
+    dy7 = torch.randn_like(ref7)
+    dref7, = torch.autograd.grad(ref7, x4, dy7)
+    w7t = SH._flipT(w7.float())
+    dx = SH._Conv(w7t, taps=(0, 32), mode=mode)(cl(dy7), n, H, W)
+    SH._Conv(w7t, taps=(32, 49), mode=mode)(cl(dy7), n, H, W, resid=dx, out=dx)
+    assert rel(uncl(dx, n, H, W), dref7) < 2e-6
+    # Downsample
+    sd = {"d.1.weight": torch.randn(12, 32, 1, 1, device=dev) * 0.3, "d.1.bias": torch.randn(12, device=dev)}
+    dn = SH._Down(sd, "d.", 8, 12)
+    xs = x0.clone().requires_grad_()
+    us = xs.reshape(n, 8, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(n, 32, H // 2, W // 2)
+    refd = F.conv2d(us, sd["d.1.weight"].double(), sd["d.1.bias"].double())
+    gotd, _, _ = dn.forward(cl(x0), n, H, W)
+    assert rel(uncl(gotd, n, H // 2, W // 2), refd) < 2e-6
+    dyd = torch.randn_like(refd)
+    drefd, = torch.autograd.grad(refd, xs, dyd)
+    assert rel(uncl(dn.backward(cl(dyd)), n, H, W), drefd) < 2e-6
+    # channels-first epilogue with an odd channel count
+    w3 = torch.randn(3, 8, 1, 1, device=dev, dtype=torch.float64)
+    out = torch.empty(n, 3, H, W, device=dev)
+    SH._Conv(w3, mode=mode)(cl(x0), n, H, W, bias=b[:3].float(), out=out, out_mode=1)
+    assert rel(out, F.conv2d(x0, w3, b[:3])) < 2e-6
+
+
+def test_groupnorm_silu_backward(dev):
+    from diffphycon_amd.model import surrogates_hip as SH
+    torch.manual_seed(1)
+    ctx = SH._Ctx(dev, 8)
+    for (B, R, Cc, use_ss) in ((3, 100, 16, True), (2, 4096, 64, False), (5, 64, 512, True), (2, 37, 8, True)):
+        x = (torch.randn(B, R, Cc, device=dev, dtype=torch.float64) * 2 + 0.5).requires_grad_()
+        ga, be = torch.randn(Cc, device=dev, dtype=torch.float64), torch.randn(Cc, device=dev, dtype=torch.float64)
+        ss = torch.randn(B, 2 * Cc, device=dev, dtype=torch.float64).requires_grad_() if use_ss else None
+        xn = F.group_norm(x.permute(0, 2, 1), 8, ga, be, eps=1e-5).permute(0, 2, 1)
+        if use_ss:
+            xn = xn * (ss[:, None, :Cc] + 1) + ss[:, None, Cc:]
+        y = F.silu(xn)
+        dy = torch.randn_like(y)
+        grads = torch.autograd.grad(y, [x, ss] if use_ss else [x], dy)
+        xf = x.detach().float().reshape(B * R, Cc).contiguous()
+        ssf = ss.detach().float().contiguous() if use_ss else None
+        st = ctx.gn_stats(xf, B, R, Cc)
+        got_y = ctx.gn_apply(xf, st, ga.float(), be.float(), ssf, B, R, Cc)
+        assert rel(got_y.reshape(B, R, Cc), y) < 2e-5
+        dx, dss = ctx.gn_bwd(xf, dy.float().reshape(B * R, Cc).contiguous(), st, ga.float(), be.float(), ssf, B, R, Cc, use_ss)
+        assert rel(dx.reshape(B, R, Cc), grads[0]) < 2e-5, (B, R, Cc)
+        if use_ss:
+            assert rel(dss, grads[1]) < 2e-5, (B, R, Cc)
+
+
+def test_layernorm_backward(dev):
+    from diffphycon_amd.model import surrogates_hip as SH
+    torch.manual_seed(2)
+    ctx = SH._Ctx(dev, 8)
+    for rows, Cc in ((1000, 8), (333, 64), (70, 512), (129, 128)):
+        x = (torch.randn(rows, Cc, device=dev, dtype=torch.float64) * 3).requires_grad_()
+        g = torch.randn(Cc, device=dev, dtype=torch.float64)
+        mean = x.mean(1, keepdim=True)
+        var = x.var(1, unbiased=False, keepdim=True)
+        y = (x - mean) * (var + 1e-5).rsqrt() * g
+        dy = torch.randn_like(y)
+        dref, = torch.autograd.grad(y, x, dy)
+        xf = x.detach().float().contiguous()
+        st = ctx.ln_stats(xf)
+        dx = ctx.ln_bwd(xf, st, g.float(), dy.float().contiguous())
+        assert rel(dx, dref) < 2e-5, (rows, Cc)
+        base = torch.randn(rows, Cc, device=dev)
+        acc = ctx.ln_bwd(xf, st, g.float(), dy.float().contiguous(), dx=base.clone())
+        assert rel(acc, dref + base.double()) < 2e-5
+
+
+def _linattn_ref(qkv, heads, n, N):
+    q, k, v = qkv.reshape(n, N, 3, heads, 32).permute(2, 0, 3, 4, 1)      # [n, heads, 32, N]
+    q = q.softmax(dim=-2) * 32 ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q)                           # [n, heads, 32, N]
+    return out.permute(0, 3, 1, 2).reshape(n * N, heads * 32)
+
+
+def test_linear_attention_backward(dev):
+    from diffphycon_amd import _lib
+    torch.manual_seed(3)
+    for n, N, heads in ((3, 256, 4), (2, 100, 2), (5, 64, 4), (2, 4096, 4)):
+        qkv = (torch.randn(n * N, 3 * heads * 32, device=dev, dtype=torch.float64) * 1.5).requires_grad_()
+        ref = _linattn_ref(qkv, heads, n, N)
+        dout = torch.randn_like(ref)
+        dref, = torch.autograd.grad(ref, qkv, dout)
+        qf, df = qkv.detach().float().contiguous(), dout.float().contiguous()
+        ws = torch.empty(max(_lib.lib().dpc_linear_attention_workspace_bytes(n, heads),
+                             _lib.lib().dpc_linear_attention_bwd_workspace_bytes(n, heads)), dtype=torch.uint8, device=dev)
+        out = torch.empty(n * N, heads * 32, device=dev)
+        _lib.check(_lib.lib().dpc_linear_attention_core(_lib.ptr(qf), _lib.ptr(out), heads, n, N, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                        _lib.stream()))
+        assert rel(out, ref) < 2e-5
+        dq = torch.full_like(qf, float("nan"))
+        _lib.check(_lib.lib().dpc_linear_attention_bwd(_lib.ptr(qf), _lib.ptr(df), _lib.ptr(dq), heads, n, N, C.c_void_p(ws.data_ptr()),
+                                                       ws.numel(), _lib.stream()))
+        HD = heads * 32
+        for j, name in enumerate("qkv"):
+            assert rel(dq[:, j * HD:(j + 1) * HD], dref[:, j * HD:(j + 1) * HD]) < 2e-5, (n, N, heads, name)
+
+
+def test_dense_attention_backward(dev):
+    from diffphycon_amd import _lib
+    torch.manual_seed(4)
+    for n, Lq, heads in ((3, 64, 4), (2, 4, 4), (2, 256, 2), (4, 50, 1)):
+        qkv = torch.randn(n * Lq, 3 * heads * 32, device=dev, dtype=torch.float64).requires_grad_()
+        q, k, v = qkv.reshape(n, Lq, 3, heads, 32).permute(2, 0, 3, 1, 4)          # [n, heads, L, 32]
+        sim = torch.einsum("bhid,bhjd->bhij", q * 32 ** -0.5, k)
+        ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(n * Lq, heads * 32)
+        dout = torch.randn_like(ref)
+        dref, = torch.autograd.grad(ref, qkv, dout)
+        qf, df = qkv.detach().float().contiguous(), dout.float().contiguous()
+        out = torch.empty(n * Lq, heads * 32, device=dev)
+        _lib.check(_lib.lib().dpc_attention_core(_lib.ptr(qf), _lib.ptr(out), heads, Lq, n, 1, Lq, 0, 1, None, None, None, _lib.stream()))
+        assert rel(out, ref) < 2e-5
+        dq = torch.full_like(qf, float("nan"))
+        _lib.check(_lib.lib().dpc_attention_bwd(_lib.ptr(qf), _lib.ptr(df), _lib.ptr(dq), heads, n, Lq, _lib.stream()))
+        assert rel(dq, dref) < 2e-5, (n, Lq, heads)
+
+
+def test_layout_and_reduction_glue(dev):
+    from diffphycon_amd import _lib
+    L, S = _lib.lib(), _lib.stream
+    torch.manual_seed(5)
+    n, Cc, H, W = 3, 3, 6, 10
+    x = torch.randn(n, Cc, H, W, device=dev)
+    y = torch.empty(n * H * W, 4, device=dev)
+    _lib.check(L.dpc_nchw_to_cl(_lib.ptr(x), _lib.ptr(y), n, Cc, 4, H * W, S()))
+    assert torch.equal(y[:, :3], cl(x)) and (y[:, 3] == 0).all()
+    z = torch.zeros(n, 5, H, W, device=dev)
+    _lib.check(L.dpc_cl_to_nchw(_lib.ptr(y), _lib.ptr(z), n, 2, 4, 1, 5, 3, 2.0, H * W, S()))
+    assert torch.equal(z[:, 3:5], 2 * x[:, 1:3]) and (z[:, :3] == 0).all()
+    _lib.check(L.dpc_channel_affine_to_cl(_lib.ptr(x), _lib.ptr(y), n, Cc, 2, 4, 3, 0.5, 1.0, H * W, S()))
+    assert torch.allclose(y[:, 3], cl(x)[:, 2] * 0.5 + 1.0, atol=1e-7)
+    m = torch.empty(n, device=dev)
+    _lib.check(L.dpc_channel_mean(_lib.ptr(x), _lib.ptr(m), n, Cc, 1, H * W, S()))
+    assert torch.allclose(m, x[:, 1].mean(dim=(1, 2)), atol=1e-6)
+    _lib.check(L.dpc_channel_fill(_lib.ptr(z), _lib.ptr(m), n, 5, 0, 0.25, H * W, S()))
+    assert torch.equal(z[:, 0], (m * 0.25)[:, None, None].expand(-1, H, W))
+    a = torch.randn(n, 50, 64, device=dev)
+    f = torch.empty(n, 64, device=dev)
+    _lib.check(L.dpc_mean_rows(_lib.ptr(a), _lib.ptr(f), n, 50, 64, S()))
+    assert torch.allclose(f, a.mean(1), atol=1e-6)
+    bc = torch.empty_like(a)
+    _lib.check(L.dpc_bcast_rows(_lib.ptr(f), _lib.ptr(bc), n, 50, 64, 0.02, S()))
+    assert torch.equal(bc, (f * 0.02)[:, None, :].expand(-1, 50, -1))
+    u = torch.randn(n, 4, 6, 8, device=dev)               # [n, H, W, C]
+    d = torch.empty(n, 2, 3, 8, device=dev)
+    _lib.check(L.dpc_downsum2x_cl(_lib.ptr(u), _lib.ptr(d), n, 2, 3, 8, S()))
+    assert torch.allclose(d, u.reshape(n, 2, 2, 3, 2, 8).sum(dim=(2, 4)), atol=1e-6)
+
+
+def _load(module, g, prefix):
+    module.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)})
+    return module
+
+
+def test_surrogate_forwards_match_the_reference_records(dev):
+    """The reference modules' recorded forward (CPU, fixture jelly_surrogates.npz) vs the HIP nets."""
+    from diffphycon_amd.model import surrogates_2d as S2
+    from diffphycon_amd.model import surrogates_hip as SH
+    g = load_golden("jelly_surrogates")
+    bd = _load(S2.Unet(dim=8, out_dim=3, dim_mults=(1, 2), channels=3), g, "wbd:").to(dev).eval()
+    hb = SH.HipUnet(bd, 16)
+    y = hb(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["dtheta"]).to(dev))
+    assert rel(y.cpu(), torch.from_numpy(g["y"])) < 2e-5
+    torch.manual_seed(int(g["fm_seed"]))
+    fm = S2.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 8), channels=4).to(dev).eval()
+    assert torch.equal(fm.init_conv.weight[0, 0].cpu(), torch.from_numpy(g["fm_first_weight"]))
+    hf = SH.HipForceUnet(fm, 8)
+    yf = hf(torch.from_numpy(g["xf"]).to(dev))
+    assert rel(yf.cpu(), torch.from_numpy(g["yf"])) < 2e-5
+
+
+@pytest.fixture(scope="module")
+def sampler_env(dev):
+    from diffphycon_amd.model import surrogates_2d as S2
+    g = load_golden("jelly_sampler")
+    bd = _load(S2.Unet(dim=8, out_dim=3, dim_mults=(1, 2), channels=3), g, "wbd:").to(dev).eval()
+    torch.manual_seed(int(g["fm_seed"]))
+    fm = S2.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 8), channels=4).to(dev).eval()
+    args = argparse.Namespace(only_vis_pressure=False, device=dev, reg_ratio=float(g["reg_ratio"]), p_min=float(g["p_min"]),
+                              p_max=float(g["p_max"]), image_size=16)
+    return g, bd, fm, args
+
+
+def test_design_gradient_matches_the_reference_record(sampler_env, dev):
+    """SURVEY 8f-2's bar: d guidance / d x within 1e-4 (relative to the gradient's max) of the reference's autograd result."""
+    from diffphycon_amd.model import surrogates_hip as SH
+    g, bd, fm, args = sampler_env
+    design = SH.HipDesignGradient(fm, bd, args)
+    bd0e = torch.from_numpy(g["bd_0"]).to(dev).unsqueeze(1).expand(-1, 4, -1, -1, -1).contiguous()
+    got = design(torch.from_numpy(g["grad:x"]).to(dev), bd0e).cpu()
+    ref = torch.from_numpy(g["grad:g"])
+    assert got.shape == ref.shape
+    for c, name in ((2, "pressure"), (3, "theta")):
+        assert rel(got[:, :, c], ref[:, :, c]) < 1e-4, name
+    assert (got[:, :, :2] == 0).all()
+    # with the regulariser off the theta gradient is the pure surrogate chain (Unet backward through every scale/shift MLP)
+    args0 = argparse.Namespace(**{**vars(args), "reg_ratio": 0.0})
+    from diffphycon_amd.diffusion import diffusion_2d_jellyfish as DJ
+    x = torch.from_numpy(g["grad:x"]).to(dev)
+    gs, gt = DJ.force_fn(x.clone(), bd0e, fm, bd, args0)
+    got0 = SH.HipDesignGradient(fm, bd, args0)(x, bd0e)
+    assert rel(got0[:, :, 3], gt) < 1e-4 and rel(got0[:, :, 2], gs[:, :, 2]) < 1e-4
+
+
+def test_design_gradient_full_width_nets_vs_autograd(dev):
+    """The configuration inference_2d_jellyfish.py builds (dim 64, mults (1,2,4,8), 4 levels incl. up-sampling and skip
+    gradients) at a reduced image size, against torch autograd through the torch surrogates."""
+    from diffphycon_amd.diffusion import diffusion_2d_jellyfish as DJ
+    from diffphycon_amd.model import surrogates_2d as S2
+    from diffphycon_amd.model import surrogates_hip as SH
+    torch.manual_seed(11)
+    fm = S2.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4).to(dev).eval()
+    bd = S2.Unet(dim=64, out_dim=3, dim_mults=(1, 2, 4, 8), channels=3).to(dev).eval()
+    for q in list(fm.parameters()) + list(bd.parameters()):
+        q.requires_grad_(False)
+    args = argparse.Namespace(only_vis_pressure=False, device=dev, reg_ratio=0.0, p_min=-1.7, p_max=2.3, image_size=32)
+    B, T = 2, 3
+    x = torch.rand(B, T, 4, 32, 32, device=dev) * 2 - 1
+    bd0e = torch.rand(B, 1, 3, 32, 32, device=dev).expand(-1, T, -1, -1, -1).contiguous()
+    gs, gt = DJ.force_fn(x.clone(), bd0e, fm, bd, args)
+    design = SH.HipDesignGradient(fm, bd, args)
+    got = design(x, bd0e)
+    assert rel(got[:, :, 2], gs[:, :, 2]) < 1e-4
+    assert rel(got[:, :, 3], gt) < 1e-4
+    # the standalone boundary-updater forward used by update_bd (diffusion_2d_jellyfish.py:849-866)
+    th = torch.rand(B * T, device=dev)
+    with torch.no_grad():
+        ref = bd(bd0e.reshape(-1, 3, 32, 32), th)
+    assert rel(design.unet(bd0e.reshape(-1, 3, 32, 32), th), ref) < 2e-5
