@@ -116,7 +116,7 @@ _SIGNATURES = {
     "dpc_linear_attention_core": (C.c_int, [_P, _P, _I, _L, _I, _P, _Z, _P]),
     "dpc_conv_pack": (C.c_int, [_P] + [_I] * 10 + [C.c_char_p, C.POINTER(_P), _P]),
     "dpc_conv_free": (None, [_P]),
-    "dpc_conv_run": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 5 + [_P, _P, _I, _I, _I, C.c_float, _P]),
+    "dpc_conv_run": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 5 + [_P, _P, _I, _I, _I, C.c_float, _I, _P]),
     "dpc_gn_workspace_bytes": (_Z, [_I, _I]),
     "dpc_gn_stats": (C.c_int, [_P, _P, _I, _L, _I, _I, _P, _Z, _P]),
     "dpc_gn_apply": (C.c_int, [_P] * 7 + [_I, _L, _I, _I, _P]),
@@ -124,7 +124,8 @@ _SIGNATURES = {
     "dpc_ln_stats": (C.c_int, [_P, _P, _L, _I, _P]),
     "dpc_ln_apply": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P]),
     "dpc_ln_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
-    "dpc_linear_attention_bwd_workspace_bytes": (_Z, [_L, _I]),
+    "dpc_linear_attention_tape_bytes": (_Z, [_L, _I]),
+    "dpc_linear_attention_fwd_save": (C.c_int, [_P, _P, _I, _L, _I, _P, _Z, _P]),
     "dpc_linear_attention_bwd": (C.c_int, [_P, _P, _P, _I, _L, _I, _P, _Z, _P]),
     "dpc_attention_bwd": (C.c_int, [_P, _P, _P, _I, _L, _I, _P]),
     "dpc_upsample2x_cl": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
@@ -138,6 +139,8 @@ _SIGNATURES = {
     "dpc_bcast_rows": (C.c_int, [_P, _P, _L, _L, _I, C.c_float, _P]),
     "dpc_add_inplace": (C.c_int, [_P, _P, _L, _P]),
     "dpc_absmax": (C.c_int, [_P, _L, _P, _P]),
+    "dpc_pad_w_cl": (C.c_int, [_P, _P, _L, _I, _I, _I, _P]),
+    "dpc_fold_w_cl": (C.c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "dpc_small_linear": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpc_burgers_fd": (C.c_int, [_P, _P, _P, _I, _I, _I, _D, _D, _D, _P]),
     "dpc_unet2d_create": (C.c_int, [C.POINTER(Unet2DCfg), C.POINTER(_P)]),

@@ -160,8 +160,10 @@ int launch_attention(const AttnParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------------ linear attention
 size_t linattn_workspace_bytes(long long images, int heads) { return (size_t)images * heads * 1024 * sizeof(float); }
 
+// ctx_stride: floats between the [32][32] context blocks of consecutive (image, head) pairs (1024: packed).  save != 0 (the
+// backward pass's tape, surr.hip): the column maximum of k and its exp-sum follow the context at +1024 / +1056.
 __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv, float* __restrict__ ctx,
-                                                          int heads, int N) {
+                                                          int heads, int N, int ctx_stride, int save) {
     __shared__ float s_max[4][32];
     __shared__ float s_z[4][32];
     __shared__ float s_acc[4][16][64];
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
     for (int r = 0; r < 16; ++r) s_acc[wave][r][lane] = acc[r];
     __syncthreads();
     if (wave == 0) {
-        float* dst = ctx + ((long long)img * heads + head) * 1024;
+        float* dst = ctx + ((long long)img * heads + head) * ctx_stride;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = rowmap(r, hh);
@@ -211,12 +213,16 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
             const float zz = (s_z[0][d] + s_z[1][d]) + (s_z[2][d] + s_z[3][d]);
             dst[d * 32 + l31] = tot / zz;
         }
+        if (save && hh == 0) {
+            dst[1024 + l31] = kmax;
+            dst[1056 + l31] = (s_z[0][l31] + s_z[1][l31]) + (s_z[2][l31] + s_z[3][l31]);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                           float* __restrict__ out, int heads, int N,
-                                                          long long total_waves, int tiles_per_img) {
+                                                          long long total_waves, int tiles_per_img, int ctx_stride) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= total_waves) return;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
             sum += e;
         }
     sum += __shfl_xor(sum, 32, 64);
-    const float* cbase = ctx + ((long long)img * heads + head) * 1024 + l31;
+    const float* cbase = ctx + ((long long)img * heads + head) * ctx_stride + l31;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -267,18 +273,18 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
 }
 
 int launch_linear_attention(const float* qkv, float* out, int heads, long long images, int N, void* ws,
-                            hipStream_t s) {
+                            hipStream_t s, int ctx_stride, int save) {
     if (images == 0) return DPC_OK;
     float* ctx = reinterpret_cast<float*>(ws);
     DPC_REQUIRE(images * heads < (1ll << 31), "linear attention: grid too large");
     const double rows_ = (double)images * N;
     ProfScope prof(PROF_LINATTN, 4.0 * rows_ * 32 * 32 * heads, 4.0 * rows_ * heads * 32 * 6, s);
-    hipLaunchKernelGGL(linattn_ctx_kernel, dim3((unsigned)(images * heads)), dim3(256), 0, s, qkv, ctx, heads, N);
+    hipLaunchKernelGGL(linattn_ctx_kernel, dim3((unsigned)(images * heads)), dim3(256), 0, s, qkv, ctx, heads, N, ctx_stride, save);
     DPC_LAUNCH_CHECK();
     const int tiles = (N + 31) / 32;
     const long long total = images * tiles * heads;
     hipLaunchKernelGGL(linattn_out_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, ctx, out, heads, N,
-                       total, tiles);
+                       total, tiles, ctx_stride);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

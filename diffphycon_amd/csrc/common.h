@@ -100,6 +100,9 @@ struct IgemmParams {
     float act_scale;        // f16x3 kernels: power-of-two scale applied to the activation operand before the fp16 split (0: 2^4),
                             // undone in the epilogue; lets a caller place a tensor of any magnitude inside the fp16 window
     float descale;          // (filled by the launcher: 1 / (act_scale * 2^12))
+    int cs0;                // elements between consecutive pixels of source 0 (filled by the launcher: C0 unless a0_stride is set)
+    int a0_stride;          // 0, or a pixel stride < C0: the C0 "channels" of a pixel are a contiguous window over the following
+                            // pixels (row-window convolution of the 7x7 stems, surr.hip)
     const float* a0;        // source 0, channels-last [B*F, Hi, Wi, C0]
     const float* a1;        // source 1 (virtual concat along channels) or null
     int C0, C1;
@@ -294,8 +297,9 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, hipStream_t s);
 size_t linattn_workspace_bytes(long long images, int heads);
+// ws: [images * heads][ctx_stride] floats; save != 0 also stores kmax / Z of the k softmax behind each context (+1024, +1056)
 int launch_linear_attention(const float* qkv, float* out, int heads, long long images, int N, void* ws,
-                            hipStream_t s);
+                            hipStream_t s, int ctx_stride = 1024, int save = 0);
 
 // ---------------------------------------------------------------- small ops (small.hip)
 // out[b][n] = out_act( bias[n] + sum_k in_act(in[b][k]) * W[n][k] ),  act: 0 none, 1 SiLU, 2 GELU(erf)

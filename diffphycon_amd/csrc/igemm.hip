@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const int c = kc * BK + acol;
         const float* src;
         int cs, cc;
-        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        if (c < p.C0) { src = p.a0; cs = p.cs0; cc = c; }
         else { src = p.a1; cs = p.C1; cc = c - p.C0; }
         const bool cok = c < K;
 #pragma unroll
@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                  p.par_b);
 }
 
-int launch_igemm(const IgemmParams& p, hipStream_t s) {
+int launch_igemm(const IgemmParams& p_in, hipStream_t s) {
+    IgemmParams p = p_in;
+    p.cs0 = p.a0_stride ? p.a0_stride : p.C0;
     DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "igemm: channel counts must be multiples of 4");
     DPC_REQUIRE(p.ntaps >= 1 && p.ntaps <= 32, "igemm: 1..32 taps");
     DPC_REQUIRE(!(p.ln_stats && (p.ntaps != 1 || p.C1 != 0)), "igemm: LayerNorm prologue needs a 1-tap single-source op");

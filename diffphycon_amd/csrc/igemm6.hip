@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm6_kernel(IgemmParams p, const uns
         const int c = kc * BK + acol;
         const float* src;
         int cs, cc;
-        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        if (c < p.C0) { src = p.a0; cs = p.cs0; cc = c; }
         else { src = p.a1; cs = p.C1; cc = c - p.C0; }
         const bool cok = c < K;
 #pragma unroll
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
         const int c = kc * BK + acol;
         const float* src;
         int cs, cc;
-        if (c < p.C0) { src = p.a0; cs = p.C0; cc = c; }
+        if (c < p.C0) { src = p.a0; cs = p.cs0; cc = c; }
         else { src = p.a1; cs = p.C1; cc = c - p.C0; }
         const bool cok = c < K;
 #pragma unroll
@@ -539,6 +539,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     IgemmParams p = p_in;
     if (p.act_scale == 0.f) p.act_scale = g3::SA;                    // f16x3 kernels: activation scale and its inverse x 2^-12
     p.descale = 1.0f / (p.act_scale * g3::SW);
+    p.cs0 = p.a0_stride ? p.a0_stride : p.C0;
     DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "igemm6: channel counts must be multiples of 4");
     DPC_REQUIRE(p.ntaps >= 1 && p.ntaps <= 32, "igemm6: 1..32 taps");
     DPC_REQUIRE(!(p.ln_stats && (p.ntaps != 1 || p.C1 != 0)), "igemm6: LayerNorm prologue needs a 1-tap single-source op");

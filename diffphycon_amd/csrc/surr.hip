@@ -34,13 +34,14 @@ __device__ __forceinline__ int rowmap_s(int r, int hh) { return (r & 3) + 8 * (r
 //   dq[n][d] = scale * p[n][d] * (dqs[n][d] - sum_d' dqs[n][d'] p[n][d'])          (p = softmax_d(q))
 //   dks[n][d] = sum_e dctx[d][e] v[n][e];  dk[n][d] = ks[n][d] * (dks[n][d] - sum_e dctx[d][e] ctx[d][e])
 //   dv[n][e] = sum_d ks[n][d] dctx[d][e]
-// workspace per (image, head): ctx[1024] | dctx[1024] | kmax[32] | Z[32] | rowdot[32] | pad  = 2176 floats
-constexpr int LAB_WS = 2176;
+// tape per (image, head), LAB_WS floats: written by the forward (dpc_linear_attention_fwd_save): ctx [d][e] | kmax[32] | Z[32];
+// by pass 1 below: rowdot[32] | ctxT [e][d] | dctx [d][e] | dctxT [e][d]   (the transposed copies make every MFMA A-operand of
+// pass 2 one contiguous 256-byte read)
+constexpr int LAB_KMAX = 1024, LAB_Z = 1056, LAB_ROWDOT = 1088, LAB_CTXT = 1152, LAB_DCTX = 2176, LAB_DCTXT = 3200, LAB_WS = 4224;
 
+// pass 1: dctx of one (image, head); 4 waves split the tokens, loads run 4 token pairs ahead of the MFMAs
 __global__ __launch_bounds__(256) void linattn_bwd_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                              float* __restrict__ ws, int heads, int N) {
-    __shared__ float s_max[4][32];
-    __shared__ float s_z[4][32];
     __shared__ float s_acc[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hh = lane >> 5;
     const long long img = blockIdx.x / heads;
@@ -48,188 +49,179 @@ __global__ __launch_bounds__(256) void linattn_bwd_ctx_kernel(const float* __res
     const int ld = 3 * heads * 32, HD = heads * 32;
     const float scale = 0.17677669529663687f;
     const float* qbase = qkv + img * N * (long long)ld + head * 32 + l31;
-    const float* kbase = qbase + HD;
-    const float* vbase = kbase + HD;
     const float* dbase = dout + img * N * (long long)HD + head * 32 + l31;
     int per = (N + 3) / 4;
-    per += per & 1;
+    per = (per + 7) & ~7;
     const int n_begin = wave * per, n_end = min(N, n_begin + per);
-
-    float m = -INFINITY;
-    for (int n = n_begin + hh; n < n_end; n += 2) m = fmaxf(m, kbase[(long long)n * ld]);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if (hh == 0) s_max[wave][l31] = m;
-    __syncthreads();
-    const float kmax = fmaxf(fmaxf(s_max[0][l31], s_max[1][l31]), fmaxf(s_max[2][l31], s_max[3][l31]));
-
-    f32x16 acc, dacc;
+    f32x16 dacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dacc[r] = 0.f; }
-    float z = 0.f;
-    for (int n0 = n_begin; n0 < n_end; n0 += 2) {
-        const int n = n0 + hh;
-        const bool ok = n < n_end;
-        const float a = ok ? expf(kbase[(long long)n * ld] - kmax) : 0.f;
-        const float b = ok ? vbase[(long long)n * ld] : 0.f;
-        z += a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        // qs[n][d] for this half-wave's token: softmax over the 32 lanes of the half
-        const float qv = ok ? qbase[(long long)n * ld] : 0.f;
-        float qm = qv;
+    for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+    for (int n0 = n_begin; n0 < n_end; n0 += 8) {
+        float qv[4], dv[4];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) qm = fmaxf(qm, __shfl_xor(qm, o, 64));
-        const float qe = expf(qv - qm);
-        float qs = qe;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) qs += __shfl_xor(qs, o, 64);
-        const float qa = ok ? (qe / qs) * scale : 0.f;
-        const float db = ok ? dbase[(long long)n * HD] : 0.f;
-        dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, db, dacc, 0, 0, 0);
-    }
-    z += __shfl_xor(z, 32, 64);
-    if (hh == 0) s_z[wave][l31] = z;
-    float* dst = ws + ((long long)img * heads + head) * LAB_WS;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_acc[wave][r][lane] = acc[r];
-    __syncthreads();
-    float cv[16];
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = rowmap_s(r, hh);
-            const float tot = (s_acc[0][r][lane] + s_acc[1][r][lane]) + (s_acc[2][r][lane] + s_acc[3][r][lane]);
-            const float zz = (s_z[0][d] + s_z[1][d]) + (s_z[2][d] + s_z[3][d]);
-            cv[r] = tot / zz;
-            dst[d * 32 + l31] = cv[r];
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + 2 * u + hh;
+            const bool ok = n < n_end;
+            qv[u] = ok ? qbase[(long long)n * ld] : 0.f;
+            dv[u] = ok ? dbase[(long long)n * HD] : 0.f;        // (a zero gradient row contributes nothing)
         }
-        if (hh == 0) {
-            dst[2048 + l31] = kmax;
-            dst[2080 + l31] = (s_z[0][l31] + s_z[1][l31]) + (s_z[2][l31] + s_z[3][l31]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // qs[n][d] for this half-wave's token: softmax over the 32 lanes of the half
+            float qm = qv[u];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) qm = fmaxf(qm, __shfl_xor(qm, o, 64));
+            const float qe = expf(qv[u] - qm);
+            float qs = qe;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) qs += __shfl_xor(qs, o, 64);
+            dacc = __builtin_amdgcn_mfma_f32_32x32x2f32((qe / qs) * scale, dv[u], dacc, 0, 0, 0);
         }
     }
-    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_acc[wave][r][lane] = dacc[r];
     __syncthreads();
     if (wave == 0) {
+        float* dst = ws + ((long long)img * heads + head) * LAB_WS;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = rowmap_s(r, hh);
             const float tot = (s_acc[0][r][lane] + s_acc[1][r][lane]) + (s_acc[2][r][lane] + s_acc[3][r][lane]);
-            dst[1024 + d * 32 + l31] = tot;
-            float rd = tot * cv[r];                              // rowdot[d] = sum_e dctx[d][e] ctx[d][e]: reduce over the 32 lanes
+            const float cv = dst[d * 32 + l31];
+            dst[LAB_DCTX + d * 32 + l31] = tot;
+            dst[LAB_DCTXT + l31 * 32 + d] = tot;
+            dst[LAB_CTXT + l31 * 32 + d] = cv;
+            float rd = tot * cv;                                 // rowdot[d] = sum_e dctx[d][e] ctx[d][e]: reduce over the 32 lanes
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) rd += __shfl_xor(rd, o, 64);
-            if (l31 == 0) dst[2112 + d] = rd;
+            if (l31 == 0) dst[LAB_ROWDOT + d] = rd;
         }
     }
 }
 
-// one wave per (image, 32-token tile, head): dq, dk, dv of the tile
+// pass 2: one workgroup per (image, 32-token tile, group of 4 heads), one wave per head.  The tile's q | k | v | dout rows are
+// staged through LDS with row-contiguous 512-byte reads and kept TRANSPOSED ([feature][token], pitch 33): every MFMA B operand
+// and every per-token softmax read is then a conflict-free row read; results replace the q | k | v slots and leave as whole rows.
+constexpr int LAB_HP = 32 * 33 + 1;              // floats per (matrix, head) slab: +1 spreads the 4 heads over distinct banks
+constexpr int LAB_LDS = 4 * 4 * LAB_HP * 4;      // bytes
 __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                              const float* __restrict__ ws, float* __restrict__ dqkv, int heads,
-                                                             int N, long long total_waves, int tiles_per_img) {
-    const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
-    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= total_waves) return;
-    const int head = (int)(wid % heads);
-    const long long rest = wid / heads;
-    const int tile = (int)(rest % tiles_per_img);
-    const long long img = rest / tiles_per_img;
+                                                             int N, int tiles_per_img) {
+    extern __shared__ float s_t[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const long long img = blockIdx.x / tiles_per_img;
+    const int tile = blockIdx.x % tiles_per_img;
+    const int h0 = blockIdx.y * 4, nh = min(4, heads - h0);
     const int ld = 3 * heads * 32, HD = heads * 32;
-    const int n = tile * 32 + l31;
-    const bool ok = n < N;
-    const long long row = img * N + (ok ? n : 0);
-    const float scale = 0.17677669529663687f;
-    const float* w = ws + ((long long)img * heads + head) * LAB_WS;
-    const float* ctx = w;
-    const float* dctx = w + 1024;
-    const float* kmaxp = w + 2048;
-    const float* zp = w + 2080;
-    const float* rdp = w + 2112;
-    const float* qrow = qkv + row * ld + head * 32;
-    const float* krow = qrow + HD;
-    const float* vrow = krow + HD;
-    const float* drow = dout + row * HD + head * 32;
-    float* oq = dqkv + row * ld + head * 32;
-
-    // ---- dq: D[d][n] = sum_e ctx[d][e] dout[n][e]    (A: lane = d, k = e parity hh; B: lane = token n)
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float a = ctx[l31 * 32 + 2 * i + hh];
-        const float b = ok ? drow[2 * i + hh] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    {
-        f32x4 q[4];
-        float m = -INFINITY;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            q[jj] = *reinterpret_cast<const f32x4*>(qrow + 8 * jj + 4 * hh);
-            m = fmaxf(fmaxf(m, fmaxf(q[jj].x, q[jj].y)), fmaxf(q[jj].z, q[jj].w));
-        }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { q[jj][s] = expf(q[jj][s] - m); sum += q[jj][s]; }
-        sum += __shfl_xor(sum, 32, 64);
-        float dot = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { q[jj][s] /= sum; dot += acc[4 * jj + s] * q[jj][s]; }
-        dot += __shfl_xor(dot, 32, 64);
-        if (ok) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                f32x4 o;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) o[s] = scale * q[jj][s] * (acc[4 * jj + s] - dot);
-                *reinterpret_cast<f32x4*>(oq + 8 * jj + 4 * hh) = o;
-            }
-        }
-    }
-    // ---- dk: D[d][n] = sum_e dctx[d][e] v[n][e];  dk = ks * (D - rowdot[d])
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float a = dctx[l31 * 32 + 2 * i + hh];
-        const float b = ok ? vrow[2 * i + hh] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    if (ok) {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(krow + 8 * jj + 4 * hh);
-            const f32x4 km = *reinterpret_cast<const f32x4*>(kmaxp + 8 * jj + 4 * hh);
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(zp + 8 * jj + 4 * hh);
-            const f32x4 rd = *reinterpret_cast<const f32x4*>(rdp + 8 * jj + 4 * hh);
-            f32x4 o;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) o[s] = (expf(kv[s] - km[s]) / zz[s]) * (acc[4 * jj + s] - rd[s]);
-            *reinterpret_cast<f32x4*>(oq + HD + 8 * jj + 4 * hh) = o;
-        }
-    }
-    // ---- dv: D[e][n] = sum_d dctx[d][e] ks[n][d]     (A: lane = e, k = d parity; B: lane = token, ks[n][d])
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const long long row0 = img * N + (long long)tile * 32;
+    const int nrows = min(32, N - tile * 32);
+    // ---- this wave's MFMA A operands (context blocks of its head) and the k-softmax statistics: issued before the staging so that
+    //      their L2 latency hides behind it (inside the MFMA loops each would cost a full round trip)
+    const int whead = h0 + (wave < nh ? wave : 0);
+    const float* w = ws + ((long long)img * heads + whead) * LAB_WS;
+    float a_ct[16], a_dt[16], a_d[16], km2[16], z2[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int d = 2 * i + hh;
-        const float a = dctx[d * 32 + l31];
-        const float b = ok ? expf(krow[d] - kmaxp[d]) / zp[d] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        a_ct[i] = w[LAB_CTXT + d * 32 + l31];
+        a_dt[i] = w[LAB_DCTXT + d * 32 + l31];
+        a_d[i] = w[LAB_DCTX + d * 32 + l31];
+        km2[i] = w[LAB_KMAX + d];
+        z2[i] = w[LAB_Z + d];
     }
-    if (ok) {
+    // ---- stage: matrix m (q, k, v, dout), 32 rows x (nh * 8) float4 chunks
+    {
+        const int j = tid & 31, rr = tid >> 5;           // chunk within the row, row within the pass (8 rows per pass)
+        const int hd = j >> 3, f0 = (j & 7) * 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float* src = m < 3 ? qkv + m * HD + h0 * 32 : dout + h0 * 32;
+            const int rl = m < 3 ? ld : HD;
+            f32x4 v[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = rr + 8 * it;
+                v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < nrows && hd < nh) v[it] = *reinterpret_cast<const f32x4*>(src + (row0 + r) * rl + 4 * j);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float* dstp = s_t + (m * 4 + hd) * LAB_HP + f0 * 33 + rr + 8 * it;
+                dstp[0] = v[it].x; dstp[33] = v[it].y; dstp[66] = v[it].z; dstp[99] = v[it].w;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < nh) {
+        const float scale = 0.17677669529663687f;
+        float* Q = s_t + (0 * 4 + wave) * LAB_HP;
+        float* K = s_t + (1 * 4 + wave) * LAB_HP;
+        float* V = s_t + (2 * 4 + wave) * LAB_HP;
+        const float* D = s_t + (3 * 4 + wave) * LAB_HP;
+        f32x4 km[4], zz[4], rd[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            km[jj] = *reinterpret_cast<const f32x4*>(w + LAB_KMAX + 8 * jj + 4 * hh);
+            zz[jj] = *reinterpret_cast<const f32x4*>(w + LAB_Z + 8 * jj + 4 * hh);
+            rd[jj] = *reinterpret_cast<const f32x4*>(w + LAB_ROWDOT + 8 * jj + 4 * hh);
+        }
+        // ---- dq: acc[d][n] = sum_e ctx[d][e] dout[n][e]
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ct[i], D[(2 * i + hh) * 33 + l31], acc, 0, 0, 0);
+        {
+            float q[16];
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q[r] = Q[rowmap_s(r, hh) * 33 + l31]; m = fmaxf(m, q[r]); }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q[r] = expf(q[r] - m); sum += q[r]; }
+            sum += __shfl_xor(sum, 32, 64);
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { q[r] /= sum; dot += acc[r] * q[r]; }
+            dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[rowmap_s(r, hh) * 33 + l31] = scale * q[r] * (acc[r] - dot);
+        }
+        // ---- dk: acc[d][n] = sum_e dctx[d][e] v[n][e];   dv: acc2[e][n] = sum_d dctx[d][e] ks[n][d]
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = 2 * i + hh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dt[i], V[d * 33 + l31], acc, 0, 0, 0);
+            const float ks = expf(K[d * 33 + l31] - km2[i]) / z2[i];
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_d[i], ks, acc2, 0, 0, 0);
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
-            *reinterpret_cast<f32x4*>(oq + 2 * HD + 8 * jj + 4 * hh) = f32x4{acc[4 * jj], acc[4 * jj + 1], acc[4 * jj + 2], acc[4 * jj + 3]};
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const int o = (8 * jj + 4 * hh + sx) * 33 + l31;
+                K[o] = (expf(K[o] - km[jj][sx]) / zz[jj][sx]) * (acc[4 * jj + sx] - rd[jj][sx]);
+                V[o] = acc2[4 * jj + sx];
+            }
+    }
+    __syncthreads();
+    {
+        const int j = tid & 31, rr = tid >> 5;
+        const int hd = j >> 3, f0 = (j & 7) * 4;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = rr + 8 * it;
+                if (r < nrows && hd < nh) {
+                    const float* sp = s_t + (m * 4 + hd) * LAB_HP + f0 * 33 + r;
+                    *reinterpret_cast<f32x4*>(dqkv + (row0 + r) * ld + m * HD + h0 * 32 + 4 * j) = f32x4{sp[0], sp[33], sp[66], sp[99]};
+                }
+            }
     }
 }
 
@@ -385,6 +377,37 @@ __global__ __launch_bounds__(256) void channel_fill_kernel(float* __restrict__ y
         y[(n * Ctot + cdst) * HW + hw] = v[n] * mul;
     }
 }
+// y[row][wpad + w][c] = x[row][w][c], zero borders: rows of W pixels -> rows of W + 2 wpad pixels
+__global__ __launch_bounds__(256) void pad_w_cl_kernel(const float* __restrict__ x, float* __restrict__ y, long long total4, int W, int C4,
+                                                      int wpad) {
+    const int Wp = W + 2 * wpad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long r = i / C4;
+        const int wp = (int)(r % Wp);
+        const long long row = r / Wp;
+        const int w = wp - wpad;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)w < (unsigned)W) v = reinterpret_cast<const f32x4*>(x)[(row * W + w) * C4 + c4];
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+// dx[row][w][c] = sum_b x[row][w + taps/2 - b][b * C + c]   (second half of the 7x7 stem's backward-data product, see _Init7)
+__global__ __launch_bounds__(256) void fold_w_cl_kernel(const float* __restrict__ x, float* __restrict__ dx, long long total, int W, int C,
+                                                       int taps) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long r = i / C;
+        const int w = (int)(r % W);
+        const long long row = r / W;
+        float s = 0.f;
+        for (int b = 0; b < taps; ++b) {
+            const int ws = w + taps / 2 - b;
+            if ((unsigned)ws < (unsigned)W) s += x[((row * W + ws) * taps + b) * C + c];
+        }
+        dx[i] = s;
+    }
+}
 // out[n][c] = mean_r x[n][r][c]   (ForceUnet head, :478-480)      one block per (n, 64-channel slab)
 __global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ out, long long R, int C) {
     __shared__ double red[4][64];
@@ -487,15 +510,16 @@ void dpc_conv_free(dpc_conv_t h) { delete h; }
 
 int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
                  int BF, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
-                 int par_b, float act_scale, dpc_stream_t stream) {
+                 int par_b, float act_scale, int a0_stride, dpc_stream_t stream) {
     DPC_REQUIRE(h && a0 && out, "conv_run: null argument");
+    DPC_REQUIRE(a0_stride == 0 || (a0_stride % 4 == 0 && a0_stride <= C0 && !a1 && !ln_stats), "conv_run: bad a0_stride");
     if (act_scale != 0.f) {
         int e = 0;
         DPC_REQUIRE(act_scale > 0.f && std::frexp(act_scale, &e) == 0.5f, "conv_run: act_scale must be a power of two (or 0)");
     }
     ModeScope scope(h->modes);
     return run_conv(h->pc, a0, a1, C0, C1, bias, resid, out, BF, 1, Hi, Wi, Ho, Wo, ln_stats, ln_gamma, out_mode, par_a, par_b,
-                    (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, act_scale);
+                    (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, act_scale, a0_stride);
 }
 
 size_t dpc_gn_workspace_bytes(int B, int C) { return std::max(gn_workspace_bytes(B, C), gn_bwd_workspace_bytes(B, C)) + 256; }
@@ -537,24 +561,36 @@ int dpc_ln_bwd(const float* x, const float* stats, const float* g, const float* 
     return launch_ln_bwd(x, stats, g, dy, dx, rows, C, accumulate, (hipStream_t)stream);
 }
 
-size_t dpc_linear_attention_bwd_workspace_bytes(int64_t images, int heads) { return (size_t)images * heads * LAB_WS * sizeof(float) + 256; }
+size_t dpc_linear_attention_tape_bytes(int64_t images, int heads) { return (size_t)images * heads * LAB_WS * sizeof(float) + 256; }
 
-int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int N, void* ws,
-                             size_t ws_bytes, dpc_stream_t stream) {
-    DPC_REQUIRE(qkv && dout && dqkv && ws && ws_bytes >= dpc_linear_attention_bwd_workspace_bytes(images, heads),
-                "linear_attention_bwd: bad argument / workspace too small");
+int dpc_linear_attention_fwd_save(const float* qkv, float* out, int heads, int64_t images, int N, void* tape, size_t tape_bytes,
+                                  dpc_stream_t stream) {
+    DPC_REQUIRE(qkv && out && tape && tape_bytes >= dpc_linear_attention_tape_bytes(images, heads),
+                "linear_attention_fwd_save: bad argument / tape too small");
+    return launch_linear_attention(qkv, out, heads, images, N, reinterpret_cast<void*>(align_up((size_t)tape, 256)), (hipStream_t)stream,
+                                   LAB_WS, 1);
+}
+
+int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int N, void* tape,
+                             size_t tape_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(qkv && dout && dqkv && tape && tape_bytes >= dpc_linear_attention_tape_bytes(images, heads),
+                "linear_attention_bwd: bad argument / tape too small");
     if (images == 0) return DPC_OK;
-    DPC_REQUIRE(images * heads < (1ll << 31), "linear_attention_bwd: grid too large");
+    const int tiles = (N + 31) / 32;
+    DPC_REQUIRE(images * heads < (1ll << 31) && images * tiles < (1ll << 31), "linear_attention_bwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    float* w = reinterpret_cast<float*>(align_up((size_t)ws, 256));
+    float* w = reinterpret_cast<float*>(align_up((size_t)tape, 256));
     const double rows_ = (double)images * N;
-    ProfScope prof(PROF_LINATTN, 12.0 * rows_ * 32 * 32 * heads, 4.0 * rows_ * heads * 32 * 14, s);
+    ProfScope prof(PROF_LINATTN, 8.0 * rows_ * 32 * 32 * heads, 4.0 * rows_ * heads * 32 * 10, s);
     hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3((unsigned)(images * heads)), dim3(256), 0, s, qkv, dout, w, heads, N);
     DPC_LAUNCH_CHECK();
-    const int tiles = (N + 31) / 32;
-    const long long total = images * tiles * heads;
-    hipLaunchKernelGGL(linattn_bwd_tok_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, qkv, dout, w, dqkv, heads, N, total,
-                       tiles);
+    static bool once = false;
+    if (!once) {
+        DPC_HIP(hipFuncSetAttribute((const void*)linattn_bwd_tok_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LAB_LDS));
+        once = true;
+    }
+    hipLaunchKernelGGL(linattn_bwd_tok_kernel, dim3((unsigned)(images * tiles), (heads + 3) / 4), dim3(256), LAB_LDS, s, qkv, dout, w, dqkv,
+                       heads, N, tiles);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
@@ -658,6 +694,24 @@ int dpc_add_inplace(float* y, const float* x, int64_t n, dpc_stream_t stream) {
     DPC_REQUIRE(y && x && n % 4 == 0, "add_inplace: bad argument");
     if (n == 0) return DPC_OK;
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, y, x, n / 4);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_pad_w_cl(const float* x, float* y, int64_t rows, int W, int C, int wpad, dpc_stream_t stream) {
+    DPC_REQUIRE(x && y && C % 4 == 0 && wpad >= 0, "pad_w_cl: bad argument");
+    const long long total4 = rows * (W + 2 * wpad) * (C / 4);
+    if (total4 == 0) return DPC_OK;
+    hipLaunchKernelGGL(pad_w_cl_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, total4, W, C / 4, wpad);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_fold_w_cl(const float* x, float* dx, int64_t rows, int W, int C, int taps, dpc_stream_t stream) {
+    DPC_REQUIRE(x && dx && taps >= 1, "fold_w_cl: bad argument");
+    const long long total = rows * W * C;
+    if (total == 0) return DPC_OK;
+    hipLaunchKernelGGL(fold_w_cl_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dx, total, W, C, taps);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

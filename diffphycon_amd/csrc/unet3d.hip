@@ -179,7 +179,7 @@ int pack_convT_parity(PackedConv& pc, const float* w, int K, int N, int a, int b
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
              const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part,
-             const float* in_coef, const float* gn_raw, const float* gn_coef, float act_scale) {
+             const float* in_coef, const float* gn_raw, const float* gn_coef, float act_scale, int a0_stride) {
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
     DPC_REQUIRE(!gn_raw || (!pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && gn_coef),
                 "conv: the fused GroupNorm residual needs the f16x3 implicit GEMM");
@@ -203,7 +203,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         return launch_conv3h(q, s);
     }
     static const int flat_ok = [] { const char* e = getenv("DPC_CONV2D_HALO"); return e ? atoi(e) : 1; }();
-    if (flat_ok && pc.flat3 && !resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo && Hi % 8 == 0 && Wi % 8 == 0 &&
+    if (flat_ok && pc.flat3 && !a0_stride && !resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo && Hi % 8 == 0 && Wi % 8 == 0 &&
         C0 % 4 == 0 && C1 % 4 == 0) {
         // (1,3,3) convolution on the halo-tile kernel: frames = the BF images (no coupling), shape-only rule (any batch size)
         Conv3hParams q{};
@@ -223,7 +223,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
     for (int i = 0; i < 32; ++i) { p.tdf[i] = pc.tdf[i]; p.tdh[i] = pc.tdh[i]; p.tdw[i] = pc.tdw[i]; }
     p.M = (long long)BF * Ho * Wo;
     p.gn_raw = gn_raw; p.gn_coef = gn_coef; p.gn_rows = (long long)F * Ho * Wo;
-    p.act_scale = act_scale;
+    p.act_scale = act_scale; p.a0_stride = a0_stride;
     if (pc.wp6g.p) {
         if (igemm_mode_default() == 2 && !ln_stats)      // (a LayerNorm prologue normalises the operand before the split)
             if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, nullptr, 0, s)) return r;

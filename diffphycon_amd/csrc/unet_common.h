@@ -56,7 +56,7 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
 int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int C1, const float* bias,
              const float* resid, float* out, int BF, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats,
              const float* ln_gamma, int out_mode, int par_a, int par_b, hipStream_t s, float* gn_part = nullptr,
-             const float* in_coef = nullptr, const float* gn_raw = nullptr, const float* gn_coef = nullptr, float act_scale = 0.f);
+             const float* in_coef = nullptr, const float* gn_raw = nullptr, const float* gn_coef = nullptr, float act_scale = 0.f, int a0_stride = 0);
 // true when run_conv can take (gn_raw, gn_coef): the f16x3 implicit GEMM with whole 128-row tiles per sample
 bool conv_can_fuse_gn_residual(const PackedConv& pc, long long rows_per_sample);
 

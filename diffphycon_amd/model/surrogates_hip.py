@@ -70,10 +70,10 @@ class _Conv:
             L.dpc_conv_free(h)
 
     def __call__(self, a0, images, Hi, Wi, a1=None, bias=None, resid=None, out=None, Ho=None, Wo=None, ln=None, out_mode=0,
-                 par=(0, 0)):
+                 par=(0, 0), C0=None, a0_stride=0):
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
-        C0 = a0.shape[-1]
+        C0 = a0.shape[-1] if C0 is None else C0
         C1 = a1.shape[-1] if a1 is not None else 0
         if self.dynamic and _Calibration.active:
             m = torch.zeros(1, device=a0.device)
@@ -87,7 +87,7 @@ class _Conv:
             out = torch.empty(rows, self.N, device=a0.device, dtype=torch.float32)
         _lib.check(_lib.lib().dpc_conv_run(self.h, _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(bias), _lib.ptr(resid), _lib.ptr(out),
                                            images, Hi, Wi, Ho, Wo, _lib.ptr(ln[0]) if ln else None, _lib.ptr(ln[1]) if ln else None,
-                                           out_mode, par[0], par[1], self.act_scale, _lib.stream()))
+                                           out_mode, par[0], par[1], self.act_scale, a0_stride, _lib.stream()))
         return out
 
 
@@ -115,20 +115,12 @@ class _Ctx:
     def __init__(self, device, groups):
         self.device, self.groups = device, groups
         self._gn_ws = None
-        self._la_ws = None
 
     def gn_ws(self, B, Cc):
         need = _lib.lib().dpc_gn_workspace_bytes(B, Cc)
         if self._gn_ws is None or self._gn_ws.numel() < need:
             self._gn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._gn_ws
-
-    def la_ws(self, images, heads):
-        need = max(_lib.lib().dpc_linear_attention_workspace_bytes(images, heads),
-                   _lib.lib().dpc_linear_attention_bwd_workspace_bytes(images, heads))
-        if self._la_ws is None or self._la_ws.numel() < need:
-            self._la_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._la_ws
 
     # ---- thin operator wrappers
     def gn_stats(self, x, B, R, Cc):
@@ -285,26 +277,25 @@ class _LinAttn:
         st1 = ctx.ln_stats(x)
         qkv = self.cq(x, n, H, W, ln=(st1, self.g1))
         att = torch.empty(x.shape[0], self.heads * 32, device=x.device)
-        ws = ctx.la_ws(n, self.heads)
-        _lib.check(_lib.lib().dpc_linear_attention_core(_lib.ptr(qkv), _lib.ptr(att), self.heads, n, H * W, C.c_void_p(ws.data_ptr()),
-                                                        ws.numel(), _lib.stream()))
+        tape = torch.empty(_lib.lib().dpc_linear_attention_tape_bytes(n, self.heads), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.lib().dpc_linear_attention_fwd_save(_lib.ptr(qkv), _lib.ptr(att), self.heads, n, H * W, C.c_void_p(tape.data_ptr()),
+                                                            tape.numel(), _lib.stream()))
         o = self.co(att, n, H, W, bias=self.bo)
         st2 = ctx.ln_stats(o)
         y = ctx.ln_apply(o, st2, self.g2, x)
-        self.tape = (x, st1, qkv, o, st2, n, H, W)
+        self.tape = (x, st1, qkv, o, st2, tape, n, H, W)
         return y
 
     def backward(self, dy):
         """dy is consumed (updated in place) and returned as dx."""
-        x, st1, qkv, o, st2, n, H, W = self.tape
+        x, st1, qkv, o, st2, tape, n, H, W = self.tape
         self.tape = None
         ctx = self.ctx
         d_o = ctx.ln_bwd(o, st2, self.g2, dy)
         d_att = self.do(d_o, n, H, W)
         dqkv = torch.empty_like(qkv)
-        ws = ctx.la_ws(n, self.heads)
         _lib.check(_lib.lib().dpc_linear_attention_bwd(_lib.ptr(qkv), _lib.ptr(d_att), _lib.ptr(dqkv), self.heads, n, H * W,
-                                                       C.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream()))
+                                                       C.c_void_p(tape.data_ptr()), tape.numel(), _lib.stream()))
         d_xn = self.dq(dqkv, n, H, W)
         return ctx.ln_bwd(x, st1, self.g1, d_xn, dx=dy)
 
@@ -405,27 +396,32 @@ class _Up:
 
 
 class _Init7:
-    """init_conv (:296, :427): 7x7, 49 taps -> two packs of <= 32 taps, the second accumulating onto the first."""
+    """init_conv (:296, :427), 7x7 on 3 / 4 channels.  As 49 taps of a 4-channel implicit GEMM it would waste 7/8 of every
+    32-wide reduction chunk; instead the 7 horizontally adjacent pixels x 4 channels = 28 contiguous floats of a width-padded
+    channels-last image are ONE reduction row (a0_stride), leaving 7 vertical taps.  The backward-data product runs the same way
+    transposed: 7 vertical taps from 64 channels to 7 x 4 horizontal partial sums per pixel, folded along w by one small kernel."""
 
     def __init__(self, sd, need_bwd):
         w = _f(sd["init_conv.weight"])
-        self.Cin = w.shape[1]
-        self.Cpad = (self.Cin + 3) // 4 * 4
-        if self.Cpad != self.Cin:
-            w = torch.cat((w, w.new_zeros(w.shape[0], self.Cpad - self.Cin, 7, 7)), dim=1)
-        self.a, self.b = _Conv(w, taps=(0, 32)), _Conv(w, taps=(32, 49))
+        Co, self.Cin = w.shape[0], w.shape[1]
+        assert self.Cin <= 4 and tuple(w.shape[2:]) == (7, 7)
+        if self.Cin != 4:
+            w = torch.cat((w, w.new_zeros(Co, 4 - self.Cin, 7, 7)), dim=1)
+        self.c = _Conv(w.permute(0, 3, 1, 2).reshape(Co, 28, 7, 1), ph=3, pw=0)            # [co][b * 4 + c][a]
         self.bias = _f(sd["init_conv.bias"])
         if need_bwd:
-            wt = _flipT(w)
-            self.da, self.db = _DConv(wt, taps=(0, 32)), _DConv(wt, taps=(32, 49))
+            self.d = _DConv(w.flip(2).permute(3, 1, 0, 2).reshape(28, Co, 7, 1), ph=3, pw=0)   # [b * 4 + c][co][6 - a]
 
     def forward(self, x, n, H, W):
-        y = self.a(x, n, H, W, bias=self.bias)
-        return self.b(x, n, H, W, resid=y, out=y)
+        xp = torch.empty(n * H * (W + 6), 4, device=x.device)
+        _lib.check(_lib.lib().dpc_pad_w_cl(_lib.ptr(x), _lib.ptr(xp), n * H, W, 4, 3, _lib.stream()))
+        return self.c(xp, n, H, W + 6, bias=self.bias, Ho=H, Wo=W, C0=28, a0_stride=4)
 
     def backward(self, dy, n, H, W):
-        dx = self.da(dy, n, H, W)
-        return self.db(dy, n, H, W, resid=dx, out=dx)
+        part = self.d(dy, n, H, W)                                                         # [rows][7 * 4]
+        dx = torch.empty(n * H * W, 4, device=dy.device)
+        _lib.check(_lib.lib().dpc_fold_w_cl(_lib.ptr(part), _lib.ptr(dx), n * H, W, 4, 7, _lib.stream()))
+        return dx
 
 
 def _encoder(ctx, sd, dims, has_time, H):

@@ -204,14 +204,16 @@ int dpc_linear_attention_core(const float* qkv, float* out, int heads, int64_t i
  * dpc_conv_run: out = conv(cat(a0[C0], a1[C1])) + bias + resid; ln_stats/ln_gamma: channel-LayerNorm prologue (:195-210)
  * for 1-tap ops; out_mode 0 [rows][N], 1 channels-first [images][N][Ho*Wo], 2 parity scatter into [images][2Ho][2Wo][N].
  * act_scale (f16x3 mode; 0 = the default 2^4): power-of-two scale applied to the input before the fp16 operand split and
- * undone in the epilogue -- the backward pass uses it to place gradients of any magnitude inside the fp16 window. */
+ * undone in the epilogue -- the backward pass uses it to place gradients of any magnitude inside the fp16 window.
+ * a0_stride (0 = C0): floats between consecutive pixels of a0 when the C0 "channels" of a pixel are a window over the
+ * following pixels -- the 7x7 stems :296 run as 7 row taps over 7 * 4 contiguous floats of a width-padded image. */
 typedef struct dpc_conv_s* dpc_conv_t;
 int dpc_conv_pack(const float* w, int N, int K, int kh, int kw, int sh, int sw, int ph, int pw, int tap_begin, int tap_end,
                   const char* mode, dpc_conv_t* out, dpc_stream_t stream);
 void dpc_conv_free(dpc_conv_t h);
 int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
                  int images, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
-                 int par_b, float act_scale, dpc_stream_t stream);
+                 int par_b, float act_scale, int a0_stride, dpc_stream_t stream);
 /* GroupNorm (:140-157 Block): stats [B][groups][2] = (mean, rstd); apply: out = SiLU(GN(x) * (scale + 1) + shift) (+ resid),
  * scale_shift [B][2C] or NULL; backward: dx and (dss != NULL) d scale_shift [B][2C] given dy. */
 size_t dpc_gn_workspace_bytes(int B, int C);
@@ -228,11 +230,15 @@ int dpc_ln_apply(const float* x, const float* stats, const float* g, const float
                  dpc_stream_t stream);
 int dpc_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, int64_t rows, int C, int accumulate,
                dpc_stream_t stream);
-/* backward of dpc_linear_attention_core (LinearAttention :232-251 without the v / (h w), which the host folds into to_out)
- * and of dpc_attention_core for whole-image sequences (Attention :266-275, L <= 256 tokens): dqkv [rows][3*heads*32]. */
-size_t dpc_linear_attention_bwd_workspace_bytes(int64_t images, int heads);
-int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int N, void* ws,
-                             size_t ws_bytes, dpc_stream_t stream);
+/* LinearAttention :232-251 (without the v / (h w), which the host folds into to_out) with a tape: the forward keeps the
+ * per-(image, head) context and the statistics of the k softmax, the backward turns (qkv, dout, tape) into dqkv
+ * [rows][3*heads*32].  dpc_attention_bwd: backward of dpc_attention_core for whole-image sequences (Attention :266-275,
+ * L <= 256 tokens). */
+size_t dpc_linear_attention_tape_bytes(int64_t images, int heads);
+int dpc_linear_attention_fwd_save(const float* qkv, float* out, int heads, int64_t images, int N, void* tape, size_t tape_bytes,
+                                  dpc_stream_t stream);
+int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int N, void* tape,
+                             size_t tape_bytes, dpc_stream_t stream);
 int dpc_attention_bwd(const float* qkv, const float* dout, float* dqkv, int heads, int64_t images, int L, dpc_stream_t stream);
 /* nearest x2 up-sampling [images][H][W][C] -> [images][2H][2W][C] (Upsample :89-93) and its backward (2 x 2 block sums) */
 int dpc_upsample2x_cl(const float* x, float* y, int images, int H, int W, int C, dpc_stream_t stream);
@@ -241,6 +247,9 @@ int dpc_downsum2x_cl(const float* dy, float* dx, int images, int H, int W, int C
 int dpc_nchw_to_cl(const float* x, float* y, int64_t N, int C, int Cpad, int64_t HW, dpc_stream_t stream);
 int dpc_cl_to_nchw(const float* x, float* y, int64_t N, int C, int Cpad, int csrc, int Ctot, int cdst, float mul, int64_t HW,
                    dpc_stream_t stream);
+/* rows of W pixels -> rows of W + 2 wpad pixels (zero borders); dx[row][w][c] = sum_b x[row][w + taps/2 - b][b*C + c] */
+int dpc_pad_w_cl(const float* x, float* y, int64_t rows, int W, int C, int wpad, dpc_stream_t stream);
+int dpc_fold_w_cl(const float* x, float* dx, int64_t rows, int W, int C, int taps, dpc_stream_t stream);
 /* y_cl[n][hw][cdst] = a * x[n][csrc][hw] + b (force_fn :96-101: un-normalised pressure into the ForceUnet input) */
 int dpc_channel_affine_to_cl(const float* x, float* y, int64_t N, int Ctot, int csrc, int Cpad, int cdst, float a, float b,
                              int64_t HW, dpc_stream_t stream);
