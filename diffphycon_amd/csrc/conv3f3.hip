@@ -600,7 +600,8 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     const bool flat = p.kd == 1;                 // (1,3,3) convolution: big-tile kernel only
     DPC_REQUIRE(!flat || (p.H % 8 == 0 && p.W % 8 == 0), "conv3f3: the (1,3,3) form needs H % 8 == 0 and W % 8 == 0");
     const int variant = flat ? 2 : conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
-    if (variant == 2 && !flat && conv3f3c_supported(pd)) return launch_conv3f3c(pd, s);     // loader-wave / persistent form
+    static const int flat_c = [] { const char* e = getenv("DPC_CONV2D_LOADER_WAVES"); return e ? atoi(e) : 1; }();
+    if (variant == 2 && (!flat || flat_c) && conv3f3c_supported(pd)) return launch_conv3f3c(pd, s);     // loader-wave / persistent form
     if (variant == 2) {
         const int tf = wide ? 4 : 8;
         const long long tiles = (long long)p.B * ((p.F + tf - 1) / tf) * (p.H / 8) * (p.W / 8);

@@ -29,7 +29,7 @@ namespace dpc {
 namespace f3c {
 constexpr int KC = 16, WROW = 64;
 constexpr int HBS = 65536;                  // byte stride between the two halo buffers (power of two: the toggle is an XOR)
-constexpr float SA = 16.0f, DESCALE = 1.0f / 65536.0f;
+constexpr float SA = 16.0f, SW = 4096.0f;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -67,16 +67,22 @@ __device__ __forceinline__ void lds_done_barrier() { asm volatile("s_waitcnt lgk
 
 // BN = 64 : 4 x 1 MFMA waves over an 8 x 8 x 8 output tile (halo 10 x 10 x 10);  BN = 128: 2 x 2 waves over 4 x 8 x 8 (6 x 10 x 10).
 // Wave (wm, wn) owns frames 2 wm, 2 wm + 1 (slab mt = frame 2 wm + (mt >> 1), rows 4 (mt & 1) .. +3) and BN / WN channels.
-template <int BN>
+// KD = 3: the 3x3x3 convolution.  KD = 1: a (1,3,3) convolution (the 2-D nets' 3x3 convs, images on the frame axis: 9 taps, no
+// frame halo) -- few taps and small K make the per-tile prologue / epilogue of conv3f3b the larger part of its time there.
+template <int BN, int KD>
 __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
     using namespace f3c;
     constexpr int WM = BN == 64 ? 4 : 2, WN = 4 / WM, MT = 4, NT = 2;
-    constexpr int TF = 2 * WM, HF = TF + 2;
+    constexpr int TF = 2 * WM, HF = TF + KD - 1, NTAPS = 9 * KD, FPAD = KD / 2;
     constexpr int NLOG = HF * 100;                      // halo points: 1000 / 600
     constexpr int HLOADS = (NLOG * 4 + 255) / 256;      // 16 / 10 quads per loader thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3c[];
     unsigned char* halo = smem_f3c;                     // two buffers at 0 and HBS
 
+    // run-time activation scale for the 2-D form only (surr.hip's calibrated backward convs); a compile-time constant in the
+    // register-tight 3-D kernel
+    const float sa = (KD == 1 && p.act_scale != 0.f) ? p.act_scale : SA;
+    const float descale = 1.0f / (sa * SW);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
             for (int i = 0; i < HLOADS; ++i) {
                 const int pt = (ltid + 256 * i) >> 2;
                 const int pf = pt / 100, ph = (pt / 10) % 10, pw = pt % 10;
-                const int f = f0 - 1 + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
+                const int f = f0 - FPAD + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
                 if (pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) hokm |= 1u << i;
                 hpt[i] = (f * p.H + h) * p.W + w;
             }
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
             for (int i = 0; i < HLOADS; ++i) {
                 if (ltid + 256 * i < NLOG * 4) {
                     uint2 p1, p2;
-                    split2(hreg[i] * SA, p1, p2);
+                    split2(hreg[i] * sa, p1, p2);
                     const int d = hdst[i] + boff;
                     *reinterpret_cast<uint2*>(halo + d) = p1;
                     *reinterpret_cast<uint2*>(halo + (d ^ 32)) = p2;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
     };
     auto ldw = [&](f16x8 (&dst)[NT][2]) {
         const unsigned char* src = wnext + wlo;
-        if (++wtap_i == 27) {
+        if (++wtap_i == NTAPS) {
             wtap_i = 0;
             if (++wkc_i == kchunks) { wkc_i = 0; ++wtile; wlane = wroot + (long long)tile_n0(wtile) * WROW; }
             wnext = wlane + wkc_i * wstride;
@@ -293,13 +299,13 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
                                     w[tap % 3][nt][PB[term]], a[2 * pr + q][PA[term]], acc[2 * pr + q][nt], 0, 0, 0);
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    if (tap < 26) lda_pair(tap + 1, pr);   // rolling A set: re-load behind the other pair's MFMAs
+                    if (tap < NTAPS - 1) lda_pair(tap + 1, pr);   // rolling A set: re-load behind the other pair's MFMAs
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
 #pragma unroll
-            for (int tap = 0; tap < 27; ++tap) tap_body(tap);
+            for (int tap = 0; tap < NTAPS; ++tap) tap_body(tap);
             // MFMA B-operand guard (see igemm6.hip): nothing may overwrite the activation fragments while the last MFMA reads them
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[mt][nt][4 * g + e] * DESCALE + bv[g][e];
+                        v[e] = acc[mt][nt][4 * g + e] * descale + bv[g][e];
                         gs[4 * g + e] += v[e];
                         gq[4 * g + e] += v[e] * v[e];
                     }
@@ -389,7 +395,7 @@ bool conv3f3c_supported(const Conv3hParams& p) {
     static const int ok = [] { const char* e = getenv("DPC_CONV3F3C"); return e ? atoi(e) : 1; }();
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     const int tf = wide ? 4 : 8;
-    return ok && p.kd != 1 && p.H % 8 == 0 && p.W % 8 == 0 && p.N % 64 == 0 && p.N == p.Npad && (p.F % tf == 0 || p.F >= 16) &&
+    return ok && p.H % 8 == 0 && p.W % 8 == 0 && p.N % 64 == 0 && p.N == p.Npad && (p.F % tf == 0 || p.F >= 16) &&
            p.C0 % 4 == 0 && p.C1 % 4 == 0;
 }
 
@@ -408,15 +414,20 @@ int launch_conv3f3c(const Conv3hParams& p, hipStream_t s) {
         DPC_HIP(hipGetDevice(&dev));
         DPC_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = std::max(8, prop.multiProcessorCount / 8 * 8);
-        DPC_HIP(hipFuncSetAttribute((const void*)conv3f3c_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
-        DPC_HIP(hipFuncSetAttribute((const void*)conv3f3c_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
+        DPC_HIP(hipFuncSetAttribute((const void*)conv3f3c_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
+        DPC_HIP(hipFuncSetAttribute((const void*)conv3f3c_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
+        DPC_HIP(hipFuncSetAttribute((const void*)conv3f3c_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
+        DPC_HIP(hipFuncSetAttribute((const void*)conv3f3c_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
         once = true;
     }
     Conv3hParams pd = p;
     pd.total_wg = (int)nwg;
     const unsigned grid = (unsigned)std::min<long long>(nwg, ncu);
-    if (wide) hipLaunchKernelGGL((conv3f3c_kernel<128>), dim3(grid), dim3(512), 2 * HBS, s, pd);
-    else hipLaunchKernelGGL((conv3f3c_kernel<64>), dim3(grid), dim3(512), 2 * HBS, s, pd);
+    if (p.kd == 1) {
+        if (wide) hipLaunchKernelGGL((conv3f3c_kernel<128, 1>), dim3(grid), dim3(512), 2 * HBS, s, pd);
+        else hipLaunchKernelGGL((conv3f3c_kernel<64, 1>), dim3(grid), dim3(512), 2 * HBS, s, pd);
+    } else if (wide) hipLaunchKernelGGL((conv3f3c_kernel<128, 3>), dim3(grid), dim3(512), 2 * HBS, s, pd);
+    else hipLaunchKernelGGL((conv3f3c_kernel<64, 3>), dim3(grid), dim3(512), 2 * HBS, s, pd);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

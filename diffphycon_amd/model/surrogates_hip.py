@@ -21,6 +21,7 @@ import os
 import torch
 
 from .. import _lib
+from ..parallel import max_scalar_over_ranks
 
 # arithmetic of the convolutions: "f16x3" (default; 22-bit operands, 3 MFMAs per product, the 3x3 convs on the LDS halo-tile
 # kernel), "x6" (bf16x6: fp32-equivalent products, 6 MFMAs, implicit GEMM only) or "f32"
@@ -35,7 +36,9 @@ class _Calibration:
     (dpc_conv_run's act_scale, undone in the epilogue).  While a calibration is active every backward convolution measures
     max |input| (one streaming pass + a host read) and sets its scale so that the maximum lands on `target`; between
     calibrations (every DPC_SURROGATE_RANGE_CHECK_EVERY design-gradient calls, default 64) the scales are reused: a tensor may
-    grow 8 x before it meets the clamp and shrink ~1e4 x before the tolerance notices."""
+    grow 8 x before it meets the clamp and shrink ~1e4 x before the tolerance notices.  With several ranks the measured maxima
+    are MAX-reduced over the ranks (parallel.max_scalar_over_ranks: one float per convolution per calibration), so the scales --
+    and with them every trajectory's bits -- do not depend on how the batch is sharded."""
     target = 512.0
     active = False
     seen = []           # (max |input|, scale) per calibrated convolution of the last calibration pass
@@ -78,7 +81,7 @@ class _Conv:
         if self.dynamic and _Calibration.active:
             m = torch.zeros(1, device=a0.device)
             _lib.check(_lib.lib().dpc_absmax(_lib.ptr(a0), a0.numel(), _lib.ptr(m), _lib.stream()))
-            m = float(m.item())
+            m = max_scalar_over_ranks(float(m.item()), a0.device)          # same scales on every rank as one process would pick
             if m > 0 and math.isfinite(m):
                 self.act_scale = 2.0 ** max(-100, min(100, round(math.log2(_Calibration.target / m))))
             _Calibration.seen.append((m, self.act_scale))

@@ -99,6 +99,6 @@ def test_jellyfish_script_two_ranks_match_single_rank(tmp_path):
     for i in range(3):
         for sub in ("thetas", "states"):
             a, b = np.load(tmp_path / "a" / sub / f"{i}.npy"), np.load(tmp_path / "b" / sub / f"{i}.npy")
-            # not bit-equal: the design gradient still runs through the two torch (MIOpen / rocBLAS) surrogate U-Nets, whose
-            # kernels pick batch-size dependent reduction orders (1 ulp seen); everything on libdpc is batch invariant
-            assert np.abs(a - b).max() <= 1e-6, (sub, i, np.abs(a - b).max())
+            # bit-equal: denoisers, update kernels and (r02) both surrogate nets forward + backward run on libdpc, whose kernels
+            # are batch invariant; the operand scales of the backward convolutions are calibrated on maxima shared by the ranks
+            assert np.array_equal(a, b), (sub, i, np.abs(a - b).max())
