@@ -157,6 +157,7 @@ struct Conv3hParams {
     const float* a1;        // virtual concat source [B,F,H,W,C1] or null
     int C0, C1;
     const float* wp;        // [27][kchunks][Npad][16]
+    const void* wpw;        // f16x3 only: Winograd-transformed pack [4][9][kchunks][Npad][2][16] fp16 (conv3w.hip) or null
     const float* bias;
     float* out;             // channels-last [B,F,H,W,N]
     int B, F, H, W;
@@ -191,6 +192,14 @@ long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad);
 // loader-wave / persistent form of the big-tile kernel (conv3f3c.hip); same GroupNorm partial-sum layout
 bool conv3f3c_supported(const Conv3hParams& p);
 int launch_conv3f3c(const Conv3hParams& p, hipStream_t s);     // GroupNorm partial-sum entries per (sample, channel)
+// Winograd F(2,3)-over-frames form of the f16x3 3x3x3 convolution (conv3w.hip): 2/3 of the matrix products of the direct kernels.
+// Taken by launch_conv3f3 when Conv3hParams::wpw is set and the shape qualifies (shape-only rule).
+bool conv3w_shape_ok(int F, int H, int W, int N, int Npad);
+bool conv3w_supported(const Conv3hParams& p);
+long long conv3w_gn_entries(int F, int H, int W);
+int launch_conv3w(const Conv3hParams& p, hipStream_t s);
+size_t conv3w_packed_bytes(int Npad, int K);
+int launch_pack_weights_w3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
 // 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6), 2: f16x3 split (conv3f3); env DPC_CONV_MODE=f32|x6|f16x3, default f16x3
 int conv_mode_default();
 

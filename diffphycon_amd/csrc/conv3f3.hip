@@ -573,6 +573,7 @@ static int conv3f3_variant(int F, int H, int W, int N, int Npad) {
 long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad) {
     using namespace f3;
     const bool wide = Npad % 128 == 0 && N > 64;
+    if (conv3w_shape_ok(F, H, W, N, Npad)) return conv3w_gn_entries(F, H, W);
     const int v = conv3f3_variant(F, H, W, N, Npad);
     if (v == 2) {
         const int tf = wide ? 4 : 8;
@@ -599,6 +600,9 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
     const bool flat = p.kd == 1;                 // (1,3,3) convolution: big-tile kernel only
     DPC_REQUIRE(!flat || (p.H % 8 == 0 && p.W % 8 == 0), "conv3f3: the (1,3,3) form needs H % 8 == 0 and W % 8 == 0");
+    if (conv3w_supported(pd)) return launch_conv3w(pd, s);        // Winograd F(2,3) over frames (conv3w.hip)
+    DPC_REQUIRE(flat || !p.gn_part || !conv3w_shape_ok(p.F, p.H, p.W, p.N, p.Npad),
+                "conv3f3: GroupNorm partial sums are laid out for the Winograd kernel but its weight pack is missing");
     const int variant = flat ? 2 : conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
     static const int flat_c = [] { const char* e = getenv("DPC_CONV2D_LOADER_WAVES"); return e ? atoi(e) : 1; }();
     if (variant == 2 && (!flat || flat_c) && conv3f3c_supported(pd)) return launch_conv3f3c(pd, s);     // loader-wave / persistent form

@@ -142,7 +142,12 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     }
     if (conv_mode_default() == 2) {
         if ((rc = pc.wp3.alloc((size_t)27 * pc.kchunks * pc.Npad * 64))) return rc;
-        return launch_pack_weights_f3(w, pc.wp3.p, N, pc.Npad, K, s);
+        if ((rc = launch_pack_weights_f3(w, pc.wp3.p, N, pc.Npad, K, s))) return rc;
+        if (N % 64 == 0 && N == pc.Npad && K % 4 == 0) {
+            if ((rc = pc.wpw.alloc(conv3w_packed_bytes(pc.Npad, K)))) return rc;
+            return launch_pack_weights_w3(w, pc.wpw.p, N, pc.Npad, K, s);
+        }
+        return DPC_OK;
     }
     if ((rc = pc.wp6.alloc((size_t)27 * pc.kchunks * pc.Npad * 96))) return rc;
     return launch_pack_weights_x6(w, pc.wp6.p, N, pc.Npad, K, s);
@@ -192,6 +197,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         q.gn_part = gn_part; q.in_coef = in_coef;
         if (conv_mode_default() == 2) {
             q.wp = reinterpret_cast<const float*>(pc.wp3.p);
+            q.wpw = pc.wpw.p;
             if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, in_coef, (long long)F * Hi * Wi, s))
                 return r;
             return launch_conv3f3(q, s);
