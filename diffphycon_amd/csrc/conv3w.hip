@@ -33,10 +33,11 @@ namespace w3 {
 constexpr float SAW = 8.0f;                 // activation pre-scale (the transformed operand is a sum of two activations)
 constexpr int TFO = 4;                      // output frames per tile
 constexpr int HFI = 6;                      // input halo frames
-constexpr int NPT = 800;                    // transformed halo points per buffer: 8 frames x 10 x 10
 constexpr int ITEMS = 400;                  // loader work items: 100 (h, w) x 4 channel quads
 }  // namespace w3
 
+// GN: the loader applies the producer's GroupNorm + (scale, shift) + SiLU (Conv3hParams::in_coef)
+template <bool GN>
 __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
     using namespace f3c;
     using namespace w3;
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w3[];
     unsigned char* halo = smem_w3;                      // two buffers at 0 and HBS
 
-    const float descale = 1.0f / (SAW * SW);
+    // operand pre-scales undone in the epilogue: activations 2^3 (plain input) or 4 log2(e) (fused GroupNorm + SiLU, see the loader)
+    const float descale = GN ? (float)(1.0 / (4.0 * 1.4426950408889634 * 4096.0)) : 1.0f / (SAW * SW);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -69,9 +71,36 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         b = t / ntf;
     };
     if (nsteps == 0) return;
+#ifdef DPC_CONV_STAMPS
+    // per wave: deltas between consecutive stamps ([0..26]) and the raw start / end clocks ([28..31]); tools/conv_stamps_w.py
+    unsigned long long tst[29];
+    int nst = 0;
+    auto stamp = [&]() { if (nst < 29) tst[nst++] = __builtin_amdgcn_s_memtime(); };
+    auto stamp_out = [&]() {
+        const unsigned long long tend = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            float* rec = p.out + ((long long)blockIdx.x * 8 + wave) * 32;
+            for (int i = 1; i < 28; ++i) rec[i - 1] = i < nst ? (float)(tst[i] - tst[i - 1]) : 0.f;
+            unsigned* ru = reinterpret_cast<unsigned*>(rec);
+            ru[28] = (unsigned)tst[0]; ru[29] = (unsigned)(tst[0] >> 32);
+            ru[30] = (unsigned)tend; ru[31] = (unsigned)(tend >> 32);
+        }
+    };
+#else
+    auto stamp = [&]() {};
+    auto stamp_out = [&]() {};
+#endif
+    stamp();
 
     if (wave >= 4) {
         // ======================================================================================= loader waves
+        // The loader shares each SIMD's VALU issue with an MFMA wave that leaves it ~5 slots per 32-cycle MFMA, and a chunk is only
+        // 216 MFMAs long: the per-chunk instruction count decides whether the matrix pipe waits.  Hence: raw buffer loads whose
+        // out-of-range lanes read 0 (no exec-mask branches, 32-bit offsets), frame validity as wave-uniform branches, ONE fused
+        // multiply-add from the raw input to the (pre-scaled) activation argument, exp2 / rcp hardware transcendentals.
+        if (p.dbg & 64) __builtin_amdgcn_s_setprio(0);
+        else if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(2);
         const int ltid = tid - 256;
         const bool two = ltid + 256 < ITEMS;              // threads 0..143 own a second item
         int hdst[2];
@@ -81,9 +110,13 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             hdst[i] = slot0(0, hw / 10, hw % 10, quad >> 1) + (quad & 1) * 8;
         }
         const int hslot = (ltid & 3) * 4;
-        unsigned hokm = 0;                                // bit 6 i + fi: input frame fi of item i is inside the tensor
-        int hpt[2];
-        const long long fstride = (long long)p.H * p.W;
+        constexpr unsigned OOB = 0xC0000000u;             // >= num_records of every buffer (conv3w_supported): the load returns 0
+        const int fstride = p.H * p.W;
+        const unsigned nrec0 = (unsigned)((long long)p.F * fstride * p.C0 * 4), nrec1 = (unsigned)((long long)p.F * fstride * p.C1 * 4);
+        // issue-stage tile state
+        int hpt[2];                                       // point index of (frame f0 - 1, h, w); may be negative
+        bool inhw[2];
+        unsigned fokm = 0;                                // wave-uniform: bit fi = input frame f0 - 1 + fi exists
         const float* xb0 = nullptr;
         const float* xb1 = nullptr;
         int b_cur = 0;
@@ -91,88 +124,179 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             int n0, w0, h0, f0, b;
             decode(j, n0, w0, h0, f0, b);
             b_cur = b;
-            xb0 = p.a0 + (long long)b * p.F * p.H * p.W * p.C0;
-            xb1 = p.a1 ? p.a1 + (long long)b * p.F * p.H * p.W * p.C1 : nullptr;
-            hokm = 0;
+            xb0 = p.a0 + (long long)b * p.F * fstride * p.C0;
+            xb1 = p.a1 ? p.a1 + (long long)b * p.F * fstride * p.C1 : nullptr;
+            fokm = 0;
+#pragma unroll
+            for (int fi = 0; fi < HFI; ++fi)
+                if ((unsigned)(f0 - 1 + fi) < (unsigned)p.F) fokm |= 1u << fi;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int hw = (ltid + 256 * i) >> 2;
                 const int h = h0 - 1 + hw / 10, w = w0 - 1 + hw % 10;
-                const bool in = (i == 0 || two) && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-#pragma unroll
-                for (int fi = 0; fi < HFI; ++fi)
-                    if (in && (unsigned)(f0 - 1 + fi) < (unsigned)p.F) hokm |= 1u << (6 * i + fi);
+                inhw[i] = (i == 0 || two) && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
                 hpt[i] = ((f0 - 1) * p.H + h) * p.W + w;
             }
         };
-        auto produce = [&](int kc, int boff) {
-            const int c = kc * KC + hslot;
-            const float* src;
-            int cs, cc;
-            if (c < p.C0) { src = xb0; cs = p.C0; cc = c; }
-            else { src = xb1; cs = p.C1; cc = c - p.C0; }
-            const bool cok = c < K;
-            f32x4 d[2][HFI];
+        // Two-stage pipeline: the raw halo of step s + 2 is requested (issue) before step s + 1 is activated, transformed, split
+        // and written (finish): the HBM / L2 latency of a chunk hides behind the VALU work and the barrier wait of the previous one.
+        // The loads are inline asm and the waits hand-counted: hipcc's own vmcnt bookkeeping degrades to vmcnt(0) across this
+        // loop's divergent `two` region and back edge, which made every finish stage wait for the loads issued just before it.
+        // No other vector-memory instruction exists on the loader path, so the count is exact: NLOADS per request, in order.
+        constexpr int NLOADS = 12 + (GN ? 5 : 0);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        auto issue = [&](int kc, f32x4 (&d)[2][HFI], f32x4 (&cf)[5]) {
+            if (GN) {
+                // the coefficient rows of this chunk are requested BEFORE the halo (in-order return)
+                const int c = kc * KC + hslot;
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b_cur * (K >> 2) + ((c < K ? c : 0) >> 2)) * 5;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int fi = 0; fi < HFI; ++fi) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (cok && ((hokm >> (6 * i + fi)) & 1))
-                        v = *reinterpret_cast<const f32x4*>(src + ((long long)hpt[i] + fi * fstride) * cs + cc);
-                    d[i][fi] = v;
-                }
-            if (p.in_coef && cok) {
-                // producer's GroupNorm + (scale + 1, shift) + SiLU (Block.forward, ...conv3d.py:196-204); the zero padding applies
-                // to the ACTIVATED tensor, so out-of-range frames / rows / columns stay 0
-                const f32x4* cf = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b_cur * (K >> 2) + (c >> 2)) * 5;
-                const f32x4 mu = cf[0], ga = cf[1], be = cf[2], sc = cf[3], sh = cf[4];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int fi = 0; fi < HFI; ++fi)
-                        if ((hokm >> (6 * i + fi)) & 1) {
-                            f32x4 y = (d[i][fi] - mu) * ga + be;
-                            y = y * sc + sh;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
-                            d[i][fi] = y;
-                        }
+                for (int i = 0; i < 5; ++i)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf[i]) : "v"(src + i) : "memory");
             }
+            const int c0 = kc * KC;                       // wave-uniform: a chunk lies in ONE source (C0 % 16 == 0 with a concat)
+            const bool s1 = c0 >= p.C0;
+            const int cs = s1 ? p.C1 : p.C0;
+            const int cc = c0 - (s1 ? p.C0 : 0) + hslot;
+            const unsigned long long base = reinterpret_cast<unsigned long long>(s1 ? xb1 : xb0);
+            i32x4 rs;                                     // raw buffer resource: base, stride 0, num_records (bytes), 32-bit data format
+            rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+            rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
+            rs.z = __builtin_amdgcn_readfirstlane((int)(s1 ? nrec1 : nrec0));
+            rs.w = 0x00020000;
+            const bool cok = c0 + hslot < K && !(p.dbg & 2);
+            const int fbytes = fstride * cs * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (i == 0 || two) {
+                const unsigned v0 = (inhw[i] && cok) ? (unsigned)((hpt[i] * cs + cc) * 4) : OOB;
 #pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const f32x4 d0 = d[i][2 * pr], d1 = d[i][2 * pr + 1], d2 = d[i][2 * pr + 2], d3 = d[i][2 * pr + 3];
-                        const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            uint2 p1, p2;
-                            split2(v[k] * SAW, p1, p2);
-                            const int dst = hdst[i] + (pr * 4 + k) * 6400 + boff;
-                            *reinterpret_cast<uint2*>(halo + dst) = p1;
-                            *reinterpret_cast<uint2*>(halo + (dst ^ 32)) = p2;
-                        }
-                    }
+                for (int fi = 0; fi < HFI; ++fi) {        // frames outside the tensor: negative / past-the-end offsets of the per-sample
+                                                          // buffer read 0 as well -- all 12 loads are unconditional
+                    const unsigned vo = v0 + (unsigned)(fi * fbytes);
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d[i][fi]) : "v"(vo), "s"(rs) : "memory");
                 }
             }
         };
-        int j = 0, kc = 0;
+        // wait until at most `newer` younger loads are in flight, i.e. until everything requested for (d, cf) has landed
+        auto landed = [&](f32x4 (&d)[2][HFI], f32x4 (&cf)[5], bool newer) {
+            if (newer) {
+                if (GN) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // (the registers pass through an empty asm so that no use of them is scheduled above the wait)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int fi = 0; fi < HFI; ++fi) asm volatile("" : "+v"(d[i][fi]));
+            if (GN) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(cf[i]));
+            }
+        };
+        // activation + transform + split + LDS write of one item.  Every instruction here displaces the co-resident MFMA wave
+        // (measured: ~6 cycles of matrix-pipe time per loader instruction, tools/conv_stamps_w.py), so the arithmetic is folded:
+        //   GN: Block.forward (...conv3d.py:196-204) is norm -> x (scale + 1) + shift -> SiLU.  With A = rstd gamma (scale + 1),
+        //       B = (beta - mu rstd gamma)(scale + 1) + shift, both times log2(e):  z = fma(x, A, B) = y log2 e,
+        //       SiLU(y) * 4 log2(e) = z * rcp(fma(exp2(-z), 1/4, 1/4)): the operand pre-scale of this kernel is 4 log2 e = 5.77
+        //       (any scale works, it is undone in the epilogue) and costs nothing.  Lanes outside the plane get A = B = 0 (the
+        //       zero padding applies to the ACTIVATED tensor), frames outside the tensor are skipped wave-uniformly.
+        //   split: hi = f16(s v) and lo = f16(s v - hi) are ONE v_fma_mix each per element (f32 x f32 + f16 -> f16), the
+        //       power-of-two pre-scale s of the un-normalised path rides along.  No clamp: |s V| > 65504 becomes inf and the output
+        //       NaN / inf -- loud, never a silently clamped product (range check: dpc_unet3d_set_range_check).
+        auto finish_item = [&](f32x4 (&d)[HFI], unsigned fok, bool in, const f32x4& Ac, const f32x4& Bc, int dst0) {
+            if (GN) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 A = in ? Ac : zero, B = in ? Bc : zero;
+#pragma unroll
+                for (int fi = 0; fi < HFI; ++fi)
+                    if ((fok >> fi) & 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = __builtin_fmaf(d[fi][e], A[e], B[e]);
+                            d[fi][e] = z * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-z), 0.25f, 0.25f));
+                        }
+                    }
+            }
+            const float sp = GN ? 1.0f : SAW;
+            // plane 1 of a point is its plane-0 address ^ 32; frame offsets are multiples of 64, so both planes take them as
+            // ds_write immediates on top of two base registers
+            unsigned char* q0 = halo + dst0;
+            unsigned char* q1 = halo + (dst0 ^ 32);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const f32x4 d0 = d[2 * pr], d1 = d[2 * pr + 1], d2 = d[2 * pr + 2], d3 = d[2 * pr + 3];
+                const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint2 p1, p2;
+                    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(p1.x) : "v"(v[k].x), "v"(v[k].y), "v"(sp));
+                    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(p1.y) : "v"(v[k].z), "v"(v[k].w), "v"(sp));
+                    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(p2.x) : "v"(v[k].x), "v"(v[k].y), "v"(sp), "v"(p1.x));
+                    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(sp), "v"(p1.y));
+                    *reinterpret_cast<uint2*>(q0 + (pr * 4 + k) * 6400) = p1;
+                    *reinterpret_cast<uint2*>(q1 + (pr * 4 + k) * 6400) = p2;
+                }
+            }
+        };
+        auto finish = [&](int kc, unsigned fok, bool in0, bool in1, f32x4 (&d)[2][HFI], const f32x4 (&cf)[5], int boff) {
+            if (p.dbg & 32) return;
+            f32x4 A = {0.f, 0.f, 0.f, 0.f}, B = A;
+            if (GN && kc * KC + hslot < K) {
+                constexpr float L2E = 1.4426950408889634f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mu = cf[0][e], ga = cf[1][e], be = cf[2][e], sc = cf[3][e], sh = cf[4][e];
+                    const float a = ga * sc;
+                    A[e] = a * L2E;
+                    B[e] = __builtin_fmaf(-mu, a, __builtin_fmaf(be, sc, sh)) * L2E;
+                }
+            }
+            finish_item(d[0], fok, in0, A, B, hdst[0] + boff);
+            if (two) finish_item(d[1], fok, in1, A, B, hdst[1] + boff);
+        };
+        struct StepState { unsigned fok; bool in0, in1; int kc; f32x4 cf[5]; };
+        f32x4 ra[2][HFI], rb[2][HFI];                     // raw halo registers of two steps in flight (roles alternate: no copies)
+        StepState sa{}, sb{};
+        int lj = 0, lkc = 0;                              // cursor of the issue stage
+        auto advance = [&]() { if (++lkc == kchunks) { lkc = 0; ++lj; setup_tile(lj < ntiles ? lj : ntiles - 1); } };
+        auto request = [&](f32x4 (&d)[2][HFI], StepState& st) {
+            issue(lkc, d, st.cf);
+            st.fok = fokm; st.in0 = inhw[0]; st.in1 = inhw[1]; st.kc = lkc;
+        };
         setup_tile(0);
-        produce(0, 0);
+        request(ra, sa);
+        if (nsteps > 1) { advance(); request(rb, sb); }
+        landed(ra, sa.cf, nsteps > 1);
+        finish(sa.kc, sa.fok, sa.in0, sa.in1, ra, sa.cf, 0);
         lds_done_barrier();                               // buffer 0 holds step 0
-        for (long long s = 0; s < nsteps; ++s) {
-            if (++kc == kchunks) { kc = 0; ++j; }
-            if (s + 1 < nsteps) {
-                if (kc == 0) setup_tile(j);
-                produce(kc, ((int)(s + 1) & 1) * HBS);    // the MFMA waves left that buffer at the previous barrier
-            }
+        stamp();
+        int ek = 0;
+        // iteration s: X = raw data of step s + 1 (requested one iteration ago); request step s + 2 into Y, finish X
+        auto body = [&](long long s, f32x4 (&X)[2][HFI], StepState& sx, f32x4 (&Y)[2][HFI], StepState& sy) {
+            if (s + 2 < nsteps) { advance(); request(Y, sy); }
+            stamp();
+            if (s + 1 < nsteps) landed(X, sx.cf, s + 2 < nsteps);
+            stamp();
+            if (s + 1 < nsteps) finish(sx.kc, sx.fok, sx.in0, sx.in1, X, sx.cf, ((int)(s + 1) & 1) * HBS);   // the MFMA waves left that buffer at the previous barrier
+            stamp();
             lds_done_barrier();
-            if (kc == 0) {                                // tile finished: the MFMA waves exchange components through buffer s & 1
-                wg_barrier(); wg_barrier(); wg_barrier(); wg_barrier();
+            stamp();
+            if (++ek == kchunks) {                        // step s closed a tile: the MFMA waves exchange components through buffer s & 1
+                ek = 0;
+                if (!(p.dbg & 8)) { wg_barrier(); wg_barrier(); wg_barrier(); wg_barrier(); }
+                stamp();
             }
+        };
+        for (long long s = 0; s < nsteps; s += 2) {
+            body(s, rb, sb, ra, sa);
+            if (s + 1 < nsteps) body(s + 1, ra, sa, rb, sb);
         }
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp_out();
         return;
     }
 
@@ -191,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
 
     // weight stream of component k: taps 0..8 of chunk 0, ..., of the last chunk, then the next tile; one wave-uniform pointer
     const long long wstride = (long long)p.Npad * WROW, wtap = wstride * kchunks;
-    const unsigned char* wroot = reinterpret_cast<const unsigned char*>(p.wpw) + (long long)wave * NTAPS * wtap;
+    const unsigned char* wroot = reinterpret_cast<const unsigned char*>(p.wpw) + (long long)((p.dbg & 4) ? 0 : wave) * NTAPS * wtap;
     const int wlo = l31 * WROW + hh * 16;
     const unsigned char* wlane = wroot;
     const unsigned char* wnext = wroot;
@@ -233,7 +357,9 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
     };
 
     const int par = wave & 1, ntr = wave >> 1;            // epilogue role: output frame parity, channel half
+    if (p.dbg & 256) __builtin_amdgcn_s_setprio(3);
     wg_barrier();                                         // step 0 is in buffer 0
+    stamp();
     for (int j = 0; j < ntiles; ++j) {
         int n0, w0, h0, f0, b;
         decode(j, n0, w0, h0, f0, b);
@@ -273,13 +399,16 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             // MFMA B-operand guard (see igemm6.hip): nothing may overwrite the activation fragments while the last MFMA reads them
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if (j < 2) stamp();
             wg_barrier();                                  // next chunk's buffer is complete; this one may be overwritten
+            if (j < 2) stamp();
             boff ^= HBS;
         }
 
         // ---- epilogue.  acc[2 pr + q][nt][4g + e] = component k of pair pr, point (rows 4q.., lane_hw(l31)), channel nt*32 + 8g + 4hh + e.
         // Exchange area = the buffer of the last chunk (boff ^ HBS after the toggle): [k][q][nt][g][lane] x 16 B = 64 KB.
         unsigned char* xch = halo + (boff ^ HBS);
+        if (p.dbg & 8) continue;
         const int nbase = n0 + ntr * 32 + 4 * hh;
         const long long tile = ((long long)(f0 / TFO) * nth + h0 / 8) * ntw + w0 / 8;
         f32x4 bv[4];
@@ -299,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                         *reinterpret_cast<f32x4*>(xch + (((((wave * 2 + q) * 2 + nt) * 4 + g) * 64 + lane) << 4)) = v;
                     }
             lds_done_barrier();
+            if (j < 2) stamp();
             f32x4 o[2][4];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -312,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                     o[q][g] = par ? (m1 - m2) - m03 : (m03 + m1) + m2;
                 }
             lds_done_barrier();
+            if (j < 2) stamp();
             const int f = f0 + 2 * pr + par;
             float gs[16], gq[16];
 #pragma unroll
@@ -361,8 +492,10 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                 }
             }
             asm volatile("" ::: "memory");
+            if (j < 2) stamp();
         }
     }
+    stamp_out();
 }
 
 static int conv3w_enabled() {
@@ -377,7 +510,10 @@ bool conv3w_shape_ok(int F, int H, int W, int N, int Npad) {
 }
 
 bool conv3w_supported(const Conv3hParams& p) {
-    return p.wpw && p.kd != 1 && conv3w_shape_ok(p.F, p.H, p.W, p.N, p.Npad) && p.C0 % 4 == 0 && p.C1 % 4 == 0 && p.act_scale == 0.f;
+    // buffer addressing of the loader: one chunk = one source, per-sample tensors below the out-of-range marker (3 GB)
+    const long long smax = (long long)p.F * p.H * p.W * std::max(p.C0, p.C1) * 4;
+    return p.wpw && p.kd != 1 && conv3w_shape_ok(p.F, p.H, p.W, p.N, p.Npad) && p.C0 % 4 == 0 && p.C1 % 4 == 0 && p.act_scale == 0.f &&
+           (p.C1 == 0 || p.C0 % 16 == 0) && smax < 0xC0000000ll - 0x40000000ll;
 }
 
 long long conv3w_gn_entries(int F, int H, int W) { return (long long)((F + 3) / 4) * (H / 8) * (W / 8) * 4; }
@@ -395,13 +531,15 @@ int launch_conv3w(const Conv3hParams& p, hipStream_t s) {
         DPC_HIP(hipGetDevice(&dev));
         DPC_HIP(hipGetDeviceProperties(&prop, dev));
         ncu = std::max(8, prop.multiProcessorCount / 8 * 8);
-        DPC_HIP(hipFuncSetAttribute((const void*)conv3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
+        DPC_HIP(hipFuncSetAttribute((const void*)conv3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
+        DPC_HIP(hipFuncSetAttribute((const void*)conv3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HBS));
         once = true;
     }
     Conv3hParams pd = p;
     pd.total_wg = (int)nwg;
     const unsigned grid = (unsigned)std::min<long long>(nwg, ncu);
-    hipLaunchKernelGGL(conv3w_kernel, dim3(grid), dim3(512), 2 * HBS, s, pd);
+    if (p.in_coef) hipLaunchKernelGGL(conv3w_kernel<true>, dim3(grid), dim3(512), 2 * HBS, s, pd);
+    else hipLaunchKernelGGL(conv3w_kernel<false>, dim3(grid), dim3(512), 2 * HBS, s, pd);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
