@@ -503,6 +503,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    from diffphycon_amd import _lib
     from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
     s128 = args.workload == "s128"
     frames, size = (64, 128) if s128 else (FRAMES, SIZE)
@@ -546,6 +547,9 @@ def main():
                           "everywhere; f16x3 = each fp32 operand split into 2 fp16 terms (22 significant bits), 3 MFMAs per "
                           "product; x6 = exact 3-way bf16 split, 6 MFMAs; f32 = native fp32 MFMA. value_exact re-times the same "
                           "loop in x6",
+            "conv3d_algorithm": _lib.lib().dpc_conv3d_algorithm().decode() + " (reported by the library: dpc_conv3d_algorithm; "
+                                "winograd_f23_frames = F(2,3) minimal filtering along the frame axis, 36 instead of 54 tap products "
+                                "per output-frame pair; roofline.achieved counts algorithmic direct-form FLOP either way)",
             "config": {"workload": f"{cfg_name}, 1000-step guided DDPM, batch={B} per GPU; one step = joint+prior Unet3D(dim 64, "
                                    "mults 1-2-4) forward + fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",
                        "global_batch": world * B, "micro_batch": mbatch, "parallelism": f"batch-shard x{world}"},

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "dpc_last_error": (C.c_char_p, []),
     "dpc_set_mode": (C.c_int, [C.c_char_p, C.c_char_p]),
     "dpc_get_mode": (C.c_char_p, [C.c_char_p]),
+    "dpc_conv3d_algorithm": (C.c_char_p, []),
     "dpc_unet3d_modes": (C.c_char_p, [_P]),
     "dpc_unet2d_modes": (C.c_char_p, [_P]),
     "dpc_unet3d_set_range_check": (C.c_int, [_P, _I]),

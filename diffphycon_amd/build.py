@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdpc.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 adds / muls into v_pk_*_f32, which beside an MFMA stream costs more
+# issue time than the two scalar ops (r02: smoke step 303.7 -> 298.5 ms with the flag; MI355X_MICROARCH.md says the same)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 # Kernels that must compile WITHOUT register spills: a spilling build of the 128-register implicit-GEMM kernel has (twice) given
 # batch-size dependent results at full size; the build fails instead of shipping one.
 NO_SPILL = {"igemm6.hip": ("igemm3_kernel",)}

@@ -93,6 +93,8 @@ const char* dpc_get_mode(const char* family) {
     return buf.c_str();
 }
 
+const char* dpc_conv3d_algorithm(void) { return conv3w_shape_ok(4, 8, 8, 64, 64) ? "winograd_f23_frames" : "direct"; }
+
 int dpc_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z, const float* init,
                           const float* rescaler, float* x_next, float* x0_out, const dpc_step_coef* coef, int B,
                           int F, int C, int H, int W, dpc_stream_t stream) {

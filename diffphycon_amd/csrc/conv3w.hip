@@ -10,9 +10,11 @@
 // i.e. four independent (1,3,3) convolutions of 9 taps per frame PAIR: 36 tap products per two output frames instead of 54
 // (2/3 of the matrix work).  (h, w) stay direct: every tap is still an LDS offset of the MFMA operand fragment.
 //   * Output tile 4 x 8 x 8 (two frame pairs), 64 output channels; 6 input frames x 10 x 10 halo per 16-channel chunk.
-//   * Loader waves 4-7: load the 6 halo frames of an (h, w, channel-quad) item, apply the producer's GroupNorm + (scale, shift) +
-//     SiLU, form V0..V3 of both pairs in fp32, pre-scale by 2^3 (|V| <= 2 |d|: same |x| <= 4094 range as the direct kernels),
-//     split into the two fp16 planes and write the 8 TRANSFORMED frames to the double-buffered swizzled halo (800 points x 64 B).
+//   * Loader waves 4-7: request the 6 halo frames of an (h, w, channel-quad) item one chunk ahead (raw buffer loads, hand-counted
+//     vmcnt), apply the producer's GroupNorm + (scale, shift) + SiLU, form V0..V3 of both pairs in fp32, split into the two fp16
+//     planes and write the 8 TRANSFORMED frames to the double-buffered swizzled halo (800 points x 64 B).  Operand pre-scale:
+//     none for a plain input, 4 log2(e) for the fused activation (it falls out of the SiLU evaluation); |V| <= 2 |d|, so the
+//     fp16 range ends at |x| = 32752 / 5676 (beyond it the operand is inf and the output NaN -- not clamped).
 //   * MFMA waves 0-3: wave k owns Winograd component k of the whole tile (4 slabs of 32 points x 64 channels, transposed
 //     accumulators exactly as conv3f3c), streams ITS transformed weights U_k ([4][9 taps][chunk][n][2 planes][16] fp16 made by
 //     launch_pack_weights_w3) with the same running pointer / 3-deep register ring, 9 taps x 24 MFMAs per chunk.
@@ -22,7 +24,8 @@
 //     loader waves join them (they would otherwise refill that buffer).
 // Rounding: U_k are formed in fp32 from the fp32 weights before the split, V_k in fp32 after the fused activation; the products
 // are the same 22-bit f16x3 products with fp32 accumulation.  F(2,3) has transform constants 1 and 1/2 only: against an fp64
-// convolution the error is that of the direct kernel within a factor ~1.5 (tests/test_gpu_ops.py, tools/f16x3_error.py).
+// convolution the error stays inside the bound the direct kernels are tested to (tests/test_gpu_ops.py: 2e-6 sqrt(27 Cin)),
+// and the full-width U-Nets agree with the oracle to the same 2e-5 as before (tests/test_gpu_unet3d.py).
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:189-204).
 #include "common.h"
 #include "f3c.h"
@@ -30,7 +33,7 @@
 namespace dpc {
 
 namespace w3 {
-constexpr float SAW = 8.0f;                 // activation pre-scale (the transformed operand is a sum of two activations)
+constexpr float SAW = 1.0f;                 // activation pre-scale of the un-normalised path (see the loader: hi = one v_cvt_pk)
 constexpr int TFO = 4;                      // output frames per tile
 constexpr int HFI = 6;                      // input halo frames
 constexpr int ITEMS = 400;                  // loader work items: 100 (h, w) x 4 channel quads
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         // loop's divergent `two` region and back edge, which made every finish stage wait for the loads issued just before it.
         // No other vector-memory instruction exists on the loader path, so the count is exact: NLOADS per request, in order.
         constexpr int NLOADS = 12 + (GN ? 5 : 0);
+        static_assert(NLOADS == (GN ? 17 : 12), "the s_waitcnt immediates in landed() are NLOADS");
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         auto issue = [&](int kc, f32x4 (&d)[2][HFI], f32x4 (&cf)[5]) {
             if (GN) {
@@ -202,8 +206,9 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         //       SiLU(y) * 4 log2(e) = z * rcp(fma(exp2(-z), 1/4, 1/4)): the operand pre-scale of this kernel is 4 log2 e = 5.77
         //       (any scale works, it is undone in the epilogue) and costs nothing.  Lanes outside the plane get A = B = 0 (the
         //       zero padding applies to the ACTIVATED tensor), frames outside the tensor are skipped wave-uniformly.
-        //   split: hi = f16(s v) and lo = f16(s v - hi) are ONE v_fma_mix each per element (f32 x f32 + f16 -> f16), the
-        //       power-of-two pre-scale s of the un-normalised path rides along.  No clamp: |s V| > 65504 becomes inf and the output
+        //   split: hi = f16(v) is one v_cvt_pk_f16_f32 per two elements, lo = f16(v - hi) ONE v_fma_mix per element (f32 + f16 ->
+        //       f16).  The un-normalised path carries no pre-scale (operands keep 22 bits down to |x| = 2^-3 and an absolute 2^-25
+        //       below: residual streams are O(1); the direct kernels' 2^4 bought 2^-29 at one more VALU op per element).  No clamp: |s V| > 65504 becomes inf and the output
         //       NaN / inf -- loud, never a silently clamped product (range check: dpc_unet3d_set_range_check).
         auto finish_item = [&](f32x4 (&d)[HFI], unsigned fok, bool in, const f32x4& Ac, const f32x4& Bc, int dst0) {
             if (GN) {
@@ -219,24 +224,29 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                         }
                     }
             }
-            const float sp = GN ? 1.0f : SAW;
             // plane 1 of a point is its plane-0 address ^ 32; frame offsets are multiples of 64, so both planes take them as
             // ds_write immediates on top of two base registers
             unsigned char* q0 = halo + dst0;
             unsigned char* q1 = halo + (dst0 ^ 32);
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const f32x4 d0 = d[2 * pr], d1 = d[2 * pr + 1], d2 = d[2 * pr + 2], d3 = d[2 * pr + 3];
-                const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+                // (element-wise on purpose: packed f32 VALU ops cost the co-resident MFMA wave more than the two scalar ops they
+                // replace -- MI355X_MICROARCH.md, "price of one filler beside MFMAs"; the file is built with -fno-slp-vectorize)
+                f32x4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = d[2 * pr][e], d1 = d[2 * pr + 1][e], d2 = d[2 * pr + 2][e], d3 = d[2 * pr + 3][e];
+                    v[0][e] = d0 - d2; v[1][e] = d1 + d2; v[2][e] = d2 - d1; v[3][e] = d1 - d3;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     uint2 p1, p2;
-                    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(p1.x) : "v"(v[k].x), "v"(v[k].y), "v"(sp));
-                    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(p1.y) : "v"(v[k].z), "v"(v[k].w), "v"(sp));
-                    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(p2.x) : "v"(v[k].x), "v"(v[k].y), "v"(sp), "v"(p1.x));
-                    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(sp), "v"(p1.y));
+                    p1.x = cvt_pk_f16(v[k].x, v[k].y);
+                    p1.y = cvt_pk_f16(v[k].z, v[k].w);
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(p2.x) : "v"(v[k].x), "v"(v[k].y), "v"(p1.x));
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(p1.y));
                     *reinterpret_cast<uint2*>(q0 + (pr * 4 + k) * 6400) = p1;
                     *reinterpret_cast<uint2*>(q1 + (pr * 4 + k) * 6400) = p2;
                 }

@@ -55,6 +55,12 @@ CONV_CASES = [
     (1, 8, 8, 8, 48, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 16, 8, 8, 20, 40, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 20, 16, 16, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),         # partial frame tile (jellyfish: 20 frames)
+    # Winograd F(2,3)-over-frames kernel (conv3w.hip: H % 8 == 0, W % 8 == 0, Cout % 64 == 0): partial tiles with an odd frame
+    # pair / an odd last frame, one-tile planes, K not a multiple of 16, several samples and column tiles
+    (1, 18, 8, 8, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 17, 8, 16, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (3, 4, 8, 8, 20, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 12, 24, 8, 72, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     # (1,3,3): the 2-D U-Net's 3x3 convolutions on the halo kernel, batch on the frame axis (any batch size, partial tiles)
     (1, 16, 16, 128, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (3, 1, 8, 64, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
