@@ -170,7 +170,7 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
         q.a0 = x_cl; q.C0 = Cin; q.wp = wp; q.bias = bias; q.out = out_cl;
         q.B = B; q.F = F; q.H = H; q.W = W; q.N = Cout; q.Npad = p.Npad; q.kchunks = (Cin + 15) / 16;
         if (conv_mode_default() == 2) {
-            if (conv3w_shape_ok(F, H, W, Cout, p.Npad) && Cin % 4 == 0) {          // Winograd pack: 36 x 64 B per (chunk, n)
+            if (conv3w_shape_ok(F, H, W, Cout, p.Npad) && Cin % 32 == 0) {          // Winograd pack: 36 x 64 B per (chunk, n)
                 int rc = launch_pack_weights_w3(w_ref, wp, Cout, p.Npad, Cin, s);
                 if (rc) return rc;
                 q.wp = nullptr; q.wpw = wp;

@@ -168,6 +168,7 @@ struct Conv3hParams {
     // GroupNorm fusion (conv3x6 only):
     float* gn_part;         // out: per-(sample, tile, frame-pair) channel sums of the conv output [B][tiles][2][N][2] (sum, sum sq)
     const float* in_coef;   // in: GroupNorm+scale/shift coefficients of the INPUT [B][K/4][5][4] (mu, rstd*gamma, beta, scale+1,
+                            //     shift), then the folded table [B][K/4][2][4] = (A, B) log2(e) (launch_gn_finalize_fused; conv3w),
                             //     shift): the halo load applies GN -> (scale, shift) -> SiLU on the fly (requires C1 == 0)
 };
 // tiles per sample of the conv3x6 output tiling (4 x 4 x 8)

@@ -36,6 +36,7 @@ namespace w3 {
 constexpr float SAW = 1.0f;                 // activation pre-scale of the un-normalised path (see the loader: hi = one v_cvt_pk)
 constexpr int TFO = 4;                      // output frames per tile
 constexpr int HFI = 6;                      // input halo frames
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int ITEMS = 400;                  // loader work items: 100 (h, w) x 4 channel quads
 }  // namespace w3
 
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         const unsigned nrec0 = (unsigned)((long long)p.F * fstride * p.C0 * 4), nrec1 = (unsigned)((long long)p.F * fstride * p.C1 * 4);
         // issue-stage tile state
         int hpt[2];                                       // point index of (frame f0 - 1, h, w); may be negative
-        bool inhw[2];
+        int inhw[2];                                      // 1: the item's (h, w) lies inside the plane (a VGPR flag: lane masks held in
+                                                          // SGPR pairs across the pipeline stages were spilling the scalar file)
         unsigned fokm = 0;                                // wave-uniform: bit fi = input frame f0 - 1 + fi exists
         const float* xb0 = nullptr;
         const float* xb1 = nullptr;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             for (int i = 0; i < 2; ++i) {
                 const int hw = (ltid + 256 * i) >> 2;
                 const int h = h0 - 1 + hw / 10, w = w0 - 1 + hw % 10;
-                inhw[i] = (i == 0 || two) && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                inhw[i] = ((i == 0 || two) && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) ? 1 : 0;
                 hpt[i] = ((f0 - 1) * p.H + h) * p.W + w;
             }
         };
@@ -146,16 +148,18 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         // The loads are inline asm and the waits hand-counted: hipcc's own vmcnt bookkeeping degrades to vmcnt(0) across this
         // loop's divergent `two` region and back edge, which made every finish stage wait for the loads issued just before it.
         // No other vector-memory instruction exists on the loader path, so the count is exact: NLOADS per request, in order.
-        constexpr int NLOADS = 12 + (GN ? 5 : 0);
-        static_assert(NLOADS == (GN ? 17 : 12), "the s_waitcnt immediates in landed() are NLOADS");
+        constexpr int NLOADS = 12 + (GN ? 2 : 0);
+        static_assert(NLOADS == (GN ? 14 : 12), "the s_waitcnt immediates in landed() are NLOADS");
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        auto issue = [&](int kc, f32x4 (&d)[2][HFI], f32x4 (&cf)[5]) {
+        auto issue = [&](int kc, f32x4 (&d)[2][HFI], f32x4 (&cf)[2]) {
             if (GN) {
-                // the coefficient rows of this chunk are requested BEFORE the halo (in-order return)
+                // the folded GroupNorm coefficients (A, B) log2(e) of this chunk's channels (second table of in_coef, see
+                // launch_gn_finalize_fused) are requested BEFORE the halo (in-order return)
                 const int c = kc * KC + hslot;
-                const f32x4* src = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b_cur * (K >> 2) + ((c < K ? c : 0) >> 2)) * 5;
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.in_coef + (long long)p.B * K * 5) +
+                                   ((long long)b_cur * (K >> 2) + ((c < K ? c : 0) >> 2)) * 2;
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                for (int i = 0; i < 2; ++i)
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(cf[i]) : "v"(src + i) : "memory");
             }
             const int c0 = kc * KC;                       // wave-uniform: a chunk lies in ONE source (C0 % 16 == 0 with a concat)
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             const int fbytes = fstride * cs * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const unsigned v0 = (inhw[i] && cok) ? (unsigned)((hpt[i] * cs + cc) * 4) : OOB;
+                const unsigned v0 = (inhw[i] != 0 && cok) ? (unsigned)((hpt[i] * cs + cc) * 4) : OOB;
 #pragma unroll
                 for (int fi = 0; fi < HFI; ++fi) {        // frames outside the tensor: negative / past-the-end offsets of the per-sample
                                                           // buffer read 0 as well -- all 12 loads are unconditional
@@ -182,9 +186,9 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             }
         };
         // wait until at most `newer` younger loads are in flight, i.e. until everything requested for (d, cf) has landed
-        auto landed = [&](f32x4 (&d)[2][HFI], f32x4 (&cf)[5], bool newer) {
+        auto landed = [&](f32x4 (&d)[2][HFI], f32x4 (&cf)[2], bool newer) {
             if (newer) {
-                if (GN) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                if (GN) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                 for (int fi = 0; fi < HFI; ++fi) asm volatile("" : "+v"(d[i][fi]));
             if (GN) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(cf[i]));
+                for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(cf[i]));
             }
         };
         // activation + transform + split + LDS write of one item.  Every instruction here displaces the co-resident MFMA wave
@@ -210,9 +214,10 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         //       f16).  The un-normalised path carries no pre-scale (operands keep 22 bits down to |x| = 2^-3 and an absolute 2^-25
         //       below: residual streams are O(1); the direct kernels' 2^4 bought 2^-29 at one more VALU op per element).  No clamp: |s V| > 65504 becomes inf and the output
         //       NaN / inf -- loud, never a silently clamped product (range check: dpc_unet3d_set_range_check).
-        auto finish_item = [&](f32x4 (&d)[HFI], unsigned fok, bool in, const f32x4& Ac, const f32x4& Bc, int dst0) {
+        auto finish_item = [&](f32x4 (&d)[HFI], unsigned fok, int inflag, const f32x4& Ac, const f32x4& Bc, int dst0) {
             if (GN) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const bool in = inflag != 0;
                 const f32x4 A = in ? Ac : zero, B = in ? Bc : zero;
 #pragma unroll
                 for (int fi = 0; fi < HFI; ++fi)
@@ -250,25 +255,97 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                     *reinterpret_cast<uint2*>(q0 + (pr * 4 + k) * 6400) = p1;
                     *reinterpret_cast<uint2*>(q1 + (pr * 4 + k) * 6400) = p2;
                 }
+                __builtin_amdgcn_sched_barrier(0);        // (one frame pair at a time: keeps the loader inside the register budget)
             }
         };
-        auto finish = [&](int kc, unsigned fok, bool in0, bool in1, f32x4 (&d)[2][HFI], const f32x4 (&cf)[5], int boff) {
+        auto finish = [&](int kc, unsigned fok, int in0, int in1, f32x4 (&d)[2][HFI], const f32x4 (&cf)[2], int boff) {
             if (p.dbg & 32) return;
-            f32x4 A = {0.f, 0.f, 0.f, 0.f}, B = A;
-            if (GN && kc * KC + hslot < K) {
-                constexpr float L2E = 1.4426950408889634f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float mu = cf[0][e], ga = cf[1][e], be = cf[2][e], sc = cf[3][e], sh = cf[4][e];
-                    const float a = ga * sc;
-                    A[e] = a * L2E;
-                    B[e] = __builtin_fmaf(-mu, a, __builtin_fmaf(be, sc, sh)) * L2E;
-                }
-            }
+            const bool cok = kc * KC + hslot < K;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 A = (GN && cok) ? cf[0] : zero, B = (GN && cok) ? cf[1] : zero;
             finish_item(d[0], fok, in0, A, B, hdst[0] + boff);
             if (two) finish_item(d[1], fok, in1, A, B, hdst[1] + boff);
         };
-        struct StepState { unsigned fok; bool in0, in1; int kc; f32x4 cf[5]; };
+        // ---- output transform + bias + GroupNorm partial sums + stores of a finished tile (see the MFMA waves' epilogue).
+        // Loader wave w takes output-frame parity w & 1 and channel half w >> 1 of both frame pairs; lane = point (lane_hw(l31) of
+        // the 4-row slab q), registers = channels 8g + 4hh + e -- the accumulator layout of the MFMA waves.
+        const int lwv = wave - 4, par = lwv & 1, ntr = lwv >> 1;
+        // Exchange layout (written by the MFMA waves): component k, channel half nt, point P = h * 8 + w of the 8 x 8 plane tile is a
+        // 128-byte row of 32 channels at ((k * 2 + nt) * 64 + P) * 128; its eight 16-byte channel quads sit at slot (quad ^ (P & 7)).
+        // A loader lane takes column w = lane >> 3 and quad j = lane & 7: eight lanes read one full row (conflict-free), and a
+        // store instruction writes 8 points x 128 contiguous bytes -- full cache lines (the accumulator layout, lane = point with 16-byte
+        // pieces of 32 rows per store, left the stores issue-bound at ~300 cycles each: tools/conv_stamps_w.py).
+        auto epilogue = [&](int j, const unsigned char* xch) {
+            int n0, w0, h0, f0, b;
+            decode(j, n0, w0, h0, f0, b);
+            const int col = lane >> 3, quad = lane & 7;
+            const int nbase = n0 + ntr * 32 + 4 * quad;
+            const long long tile = ((long long)(f0 / TFO) * nth + h0 / 8) * ntw + w0 / 8;
+            const unsigned char* xl = xch + (ntr * 64 + col) * 128 + ((quad ^ col) << 4);
+            // combine the three components of this wave's output frame (between the two barriers that fence the buffer): row i = h
+            auto gather = [&](f32x4 (&o)[8]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    auto rd = [&](int k) { return *reinterpret_cast<const f32x4*>(xl + k * 16384 + i * 1024); };
+                    const f32x4 m1 = rd(1), m2 = rd(2);
+                    const f32x4 m03 = rd(par ? 3 : 0);
+                    o[i] = par ? (m1 - m2) - m03 : (m03 + m1) + m2;
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);      // (at most 6 reads in flight: registers)
+                }
+            };
+            // de-scale + bias, GroupNorm partial sums of the OUTPUT (this lane: 4 channels x 8 rows of one column), dwordx4 stores
+            // (asm: the stores must not enter hipcc's vmcnt bookkeeping of this path -- see landed(); they retire in order with the
+            // loads, so a later vmcnt(12 | 14) also waits for them), then the sums over the 8 columns (lane bits 3-5) and one
+            // 32-byte row of GroupNorm partial-sum entry 2 pr + par of the tile per quad.
+            auto emit = [&](int pr, const f32x4 (&o)[8]) {
+                const int f = f0 + 2 * pr + par;
+                float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (f < p.F) {
+                    const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbase) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    float* base = p.out + ((((long long)b * p.F + f) * p.H + h0) * p.W + w0 + col) * p.N + nbase;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = o[i][e] * descale + bv[e];
+                            gs[e] += v[e];
+                            gq[e] += v[e] * v[e];
+                        }
+                        // (s_nop: a VALU write to the data registers of a >64-bit store needs 2 wait states, and the hazard
+                        // recogniser does not look into inline asm)
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(base + (long long)i * p.W * p.N), "v"(v) : "memory");
+                    }
+                }
+                if (p.gn_part) {
+#pragma unroll
+                    for (int m = 8; m <= 32; m <<= 1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gs[e] += __shfl_xor(gs[e], m, 64);
+                            gq[e] += __shfl_xor(gq[e], m, 64);
+                        }
+                    if (lane < 8) {
+                        float* gdst = p.gn_part + ((((long long)b * ((long long)ntf * nth * ntw) + tile) * 4 + 2 * pr + par) * p.N + nbase) * 2;
+                        const f32x4 t0 = {gs[0], gq[0], gs[1], gq[1]}, t1 = {gs[2], gq[2], gs[3], gq[3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(gdst), "v"(t0) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(gdst + 4), "v"(t1) : "memory");
+                    }
+                }
+            };
+            f32x4 o0[8], o1[8];
+            wg_barrier();                                  // E1: pair 0 is in LDS
+            gather(o0);
+            lds_done_barrier();                            // E2: the MFMA waves may overwrite it with pair 1
+            wg_barrier();                                  // E3
+            gather(o1);
+            lds_done_barrier();                            // E4: the buffer returns to the halo pipeline; the MFMA waves go on
+            stamp();
+            emit(0, o0);
+            stamp();
+            emit(1, o1);
+        };
+        struct StepState { unsigned fok; int in0, in1; int kc; f32x4 cf[2]; };
         f32x4 ra[2][HFI], rb[2][HFI];                     // raw halo registers of two steps in flight (roles alternate: no copies)
         StepState sa{}, sb{};
         int lj = 0, lkc = 0;                              // cursor of the issue stage
@@ -284,26 +361,28 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         finish(sa.kc, sa.fok, sa.in0, sa.in1, ra, sa.cf, 0);
         lds_done_barrier();                               // buffer 0 holds step 0
         stamp();
-        int ek = 0;
-        // iteration s: X = raw data of step s + 1 (requested one iteration ago); request step s + 2 into Y, finish X
-        auto body = [&](long long s, f32x4 (&X)[2][HFI], StepState& sx, f32x4 (&Y)[2][HFI], StepState& sy) {
+        // iteration s: X = raw data of step s + 1 (requested one iteration ago); request step s + 2 into Y, finish X.  A tile is an
+        // EVEN number of steps (conv3w_supported: K % 32 == 0), so the two register sets alternate without copies, the epilogue
+        // exists once in the code and the buffer a tile leaves behind is always buffer 1.
+        auto body = [&](long long s, f32x4 (&X)[2][HFI], StepState& sx, f32x4 (&Y)[2][HFI], StepState& sy, int boff) {
             if (s + 2 < nsteps) { advance(); request(Y, sy); }
             stamp();
             if (s + 1 < nsteps) landed(X, sx.cf, s + 2 < nsteps);
             stamp();
-            if (s + 1 < nsteps) finish(sx.kc, sx.fok, sx.in0, sx.in1, X, sx.cf, ((int)(s + 1) & 1) * HBS);   // the MFMA waves left that buffer at the previous barrier
+            if (s + 1 < nsteps) finish(sx.kc, sx.fok, sx.in0, sx.in1, X, sx.cf, boff);   // the MFMA waves left that buffer at the previous barrier
             stamp();
             lds_done_barrier();
             stamp();
-            if (++ek == kchunks) {                        // step s closed a tile: the MFMA waves exchange components through buffer s & 1
-                ek = 0;
-                if (!(p.dbg & 8)) { wg_barrier(); wg_barrier(); wg_barrier(); wg_barrier(); }
-                stamp();
-            }
         };
-        for (long long s = 0; s < nsteps; s += 2) {
-            body(s, rb, sb, ra, sa);
-            if (s + 1 < nsteps) body(s + 1, ra, sa, rb, sb);
+        long long s = 0;
+        for (int j = 0; j < ntiles; ++j) {
+            for (int kc = 0; kc < kchunks; kc += 2) {
+                body(s, rb, sb, ra, sa, HBS);
+                body(s + 1, ra, sa, rb, sb, 0);
+                s += 2;
+            }
+            if (!(p.dbg & 8)) epilogue(j, halo + HBS);
+            stamp();
         }
         __builtin_amdgcn_s_waitcnt(0);
         stamp_out();
@@ -366,8 +445,6 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         }
     };
 
-    const int par = wave & 1, ntr = wave >> 1;            // epilogue role: output frame parity, channel half
-    if (p.dbg & 256) __builtin_amdgcn_s_setprio(3);
     wg_barrier();                                         // step 0 is in buffer 0
     stamp();
     for (int j = 0; j < ntiles; ++j) {
@@ -416,15 +493,15 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         }
 
         // ---- epilogue.  acc[2 pr + q][nt][4g + e] = component k of pair pr, point (rows 4q.., lane_hw(l31)), channel nt*32 + 8g + 4hh + e.
-        // Exchange area = the buffer of the last chunk (boff ^ HBS after the toggle): [k][q][nt][g][lane] x 16 B = 64 KB.
+        // The output transform crosses waves AND is done by the loader waves (they idle here anyway, and a tile's 128 KB of output
+        // stores -- issue-bound while every CU bursts at once -- then drain beside the next tile's MFMAs instead of in front of
+        // them): per frame pair the four MFMA waves park their component in the buffer of the last chunk (boff ^ HBS after the
+        // toggle; 64 KB, layout at the loader's epilogue), the loader waves read and combine it between two barriers.
         unsigned char* xch = halo + (boff ^ HBS);
         if (p.dbg & 8) continue;
-        const int nbase = n0 + ntr * 32 + 4 * hh;
-        const long long tile = ((long long)(f0 / TFO) * nth + h0 / 8) * ntw + w0 / 8;
-        f32x4 bv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bv[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbase + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // (row of point P = (4 q + lh) * 8 + lw; this lane's quads 2 g + hh go to slot (2 g + hh) ^ (P & 7) = 2 g ^ (hh ^ lw))
+        unsigned char* xw = xch + (wave * 128 + lh * 8 + lw) * 128;
+        const int tsw = hh ^ lw;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
 #pragma unroll
@@ -435,73 +512,11 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 v = {acc[2 * pr + q][nt][4 * g], acc[2 * pr + q][nt][4 * g + 1], acc[2 * pr + q][nt][4 * g + 2],
                                          acc[2 * pr + q][nt][4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(xch + (((((wave * 2 + q) * 2 + nt) * 4 + g) * 64 + lane) << 4)) = v;
+                        *reinterpret_cast<f32x4*>(xw + nt * 8192 + q * 4096 + ((tsw ^ (2 * g)) << 4)) = v;
                     }
-            lds_done_barrier();
+            lds_done_barrier();                            // E1 / E3: pair pr is in LDS
             if (j < 2) stamp();
-            f32x4 o[2][4];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    auto rd = [&](int k) {
-                        return *reinterpret_cast<const f32x4*>(xch + (((((k * 2 + q) * 2 + ntr) * 4 + g) * 64 + lane) << 4));
-                    };
-                    const f32x4 m1 = rd(1), m2 = rd(2);
-                    const f32x4 m03 = rd(par ? 3 : 0);
-                    o[q][g] = par ? (m1 - m2) - m03 : (m03 + m1) + m2;
-                }
-            lds_done_barrier();
-            if (j < 2) stamp();
-            const int f = f0 + 2 * pr + par;
-            float gs[16], gq[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gs[r] = 0.f; gq[r] = 0.f; }
-            if (f < p.F) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float* base = p.out + ((((long long)b * p.F + f) * p.H + h0 + 4 * q + lh) * p.W + w0 + lw) * p.N + nbase;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = o[q][g][e] * descale + bv[g][e];
-                            gs[4 * g + e] += v[e];
-                            gq[4 * g + e] += v[e] * v[e];
-                        }
-                        *reinterpret_cast<f32x4*>(base + 8 * g) = v;
-                    }
-                }
-            }
-            if (p.gn_part) {
-                // GroupNorm statistics of the OUTPUT: per channel, this wave's 2 slabs x 32 points of frame f (zeros for a frame past
-                // the end).  Transpose tree over the 32 lanes of a half-wave as in conv3f3c; entry = 2 pr + par of the tile.
-                float* gdst = p.gn_part + (((long long)b * ((long long)ntf * nth * ntw) + tile) * 4 + 2 * pr + par) * p.N * 2;
-                float tot[2];
-#pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    float* x = which ? gq : gs;
-#pragma unroll
-                    for (int half = 8; half >= 1; half >>= 1) {
-                        const bool up = (l31 & (half * 2)) != 0;
-#pragma unroll
-                        for (int i = 0; i < half; ++i) {
-                            const float send = up ? x[i] : x[i + half];
-                            const float keep = up ? x[i + half] : x[i];
-                            x[i] = keep + __shfl_xor(send, half * 2, 64);
-                        }
-                    }
-                    tot[which] = x[0] + __shfl_xor(x[0], 1, 64);
-                }
-                if ((l31 & 1) == 0) {
-                    const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + ((l31 >> 1) & 1);
-                    const int n = n0 + ntr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    gdst[n * 2] = tot[0];
-                    gdst[n * 2 + 1] = tot[1];
-                }
-            }
-            asm volatile("" ::: "memory");
+            wg_barrier();                                  // E2 / E4: the loader waves have read it
             if (j < 2) stamp();
         }
     }
@@ -523,7 +538,7 @@ bool conv3w_supported(const Conv3hParams& p) {
     // buffer addressing of the loader: one chunk = one source, per-sample tensors below the out-of-range marker (3 GB)
     const long long smax = (long long)p.F * p.H * p.W * std::max(p.C0, p.C1) * 4;
     return p.wpw && p.kd != 1 && conv3w_shape_ok(p.F, p.H, p.W, p.N, p.Npad) && p.C0 % 4 == 0 && p.C1 % 4 == 0 && p.act_scale == 0.f &&
-           (p.C1 == 0 || p.C0 % 16 == 0) && smax < 0xC0000000ll - 0x40000000ll;
+           (p.C1 == 0 || p.C0 % 16 == 0) && (p.C0 + p.C1) % 32 == 0 && smax < 0xC0000000ll - 0x40000000ll;
 }
 
 long long conv3w_gn_entries(int F, int H, int W) { return (long long)((F + 3) / 4) * (H / 8) * (W / 8) * 4; }

@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
 
 // ---- fused-statistics path: the conv3x6 epilogue already produced per-tile channel sums (Conv3hParams::gn_part)
 // one wave per (sample, group): fold [tiles][2][C][2] fp32 partials in fp64 (fixed order), emit (mean, rstd) and the
-// per-channel coefficient table [B][C/4][5][4] = (mu, rstd*gamma, beta, scale+1, shift) for the consumer's halo load
+// per-channel coefficient table [B][C/4][5][4] = (mu, rstd*gamma, beta, scale+1, shift) for the consumer's halo load, followed by
+// its folded form [B][C/4][2][4] (coef must hold B * C * 7 floats)
 __global__ __launch_bounds__(1024) void gn_finalize_fused_kernel(const float* __restrict__ part, float* __restrict__ stats,
                                                                 float* __restrict__ coef, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
@@ -282,6 +283,12 @@ __global__ __launch_bounds__(1024) void gn_finalize_fused_kernel(const float* __
             dst[8] = beta[ch];
             dst[12] = scale_shift ? scale_shift[(long long)b * 2 * C + ch] + 1.0f : 1.0f;
             dst[16] = scale_shift ? scale_shift[(long long)b * 2 * C + C + ch] : 0.0f;
+            // folded form behind the table, [B][C/4][2][4] at coef + B C 5, for the Winograd conv's loader (conv3w.hip):
+            // GroupNorm -> x (scale + 1) + shift as ONE multiply-add y = x A + B, both times log2(e) (the exponent of its SiLU)
+            const double ga = (double)dst[4], sc = (double)dst[12];
+            float* d2 = coef + (long long)B * C * 5 + ((long long)b * (C >> 2) + (ch >> 2)) * 8 + (ch & 3);
+            d2[0] = (float)(ga * sc * 1.4426950408889634);
+            d2[4] = (float)((((double)dst[8] - (double)mu * ga) * sc + (double)dst[16]) * 1.4426950408889634);
         }
     }
 }

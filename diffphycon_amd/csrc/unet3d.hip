@@ -143,7 +143,7 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     if (conv_mode_default() == 2) {
         if ((rc = pc.wp3.alloc((size_t)27 * pc.kchunks * pc.Npad * 64))) return rc;
         if ((rc = launch_pack_weights_f3(w, pc.wp3.p, N, pc.Npad, K, s))) return rc;
-        if (N % 64 == 0 && N == pc.Npad && K % 4 == 0) {
+        if (N % 64 == 0 && N == pc.Npad && K % 32 == 0) {
             if ((rc = pc.wpw.alloc(conv3w_packed_bytes(pc.Npad, K)))) return rc;
             return launch_pack_weights_w3(w, pc.wpw.p, N, pc.Npad, K, s);
         }
@@ -318,7 +318,7 @@ struct Runner {
             float* raw1 = ar.allocf(P * Cout);
             float* part = ar.allocf((long long)mb * tiles * 2 * Cout * 2);
             float* stats = ar.allocf((long long)mb * Cout * 2);
-            float* coef = ar.allocf((long long)mb * Cout * 5);
+            float* coef = ar.allocf((long long)mb * Cout * 7);          // 5-row table + its folded 2-row form (launch_gn_finalize_fused)
             float* raw2 = (same && dst == x0) ? ar.allocf(P * Cout) : dst;      // (allocated in the dry run as well)
             const PackedConv* c1 = conv(p + ".block1.proj.weight");
             const PackedConv* c2 = conv(p + ".block2.proj.weight");

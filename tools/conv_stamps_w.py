@@ -43,15 +43,16 @@ for (B, Fr, H, W, Ci, Co) in [(8, 32, 64, 64, 64, 64), (8, 32, 32, 32, 128, 128)
         for kc in range(kch):
             names += [f"t{j}c{kc}_taps", f"t{j}c{kc}_wait"]
         for pr in range(2):
-            names += [f"t{j}p{pr}_write+bar", f"t{j}p{pr}_read+bar", f"t{j}p{pr}_store"]
+            names += [f"t{j}p{pr}_write+bar", f"t{j}p{pr}_loader_reads"]
     names = names[:27]
     print(f"{Ci}->{Co} @{H}: launch {us:.1f} us; MFMA wave lifetime mean {dur[:, :4].mean():.0f} cycles -> {dur[:, :4].mean() / us / 1e3:.3f} GHz "
           f"effective; ideal taps/chunk = {9 * 24 * 32}; tiles per workgroup {B * (Fr // 4) * (H // 8) * (W // 8) * (Co // 64) / 256:.1f}")
     print("   MFMA: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, mf)))
     lnames = ["first_produce+bar"]
-    for s in range(13):
+    for s in range(kch):
         lnames += [f"s{s}_request", f"s{s}_landed", f"s{s}_finish", f"s{s}_wait"]
-        if (s + 1) % kch == 0:
-            lnames += [f"s{s}_epilogue_bars"]
+    lnames += ["ep_barriers+gather", "ep_emit0", "ep_emit1"]
+    for s in range(kch, 2 * kch):
+        lnames += [f"s{s}_request", f"s{s}_landed", f"s{s}_finish", f"s{s}_wait"]
     for wv in range(4):
         print(f"   loader wave {wv}: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(lnames[:27], ld[wv].tolist())))
