@@ -227,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                             const float z = __builtin_fmaf(d[fi][e], A[e], B[e]);
                             d[fi][e] = z * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-z), 0.25f, 0.25f));
                         }
+                        if (fi & 1) __builtin_amdgcn_sched_barrier(0);
                     }
             }
             // plane 1 of a point is its plane-0 address ^ 32; frame offsets are multiples of 64, so both planes take them as
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                         : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(p1.y));
                     *reinterpret_cast<uint2*>(q0 + (pr * 4 + k) * 6400) = p1;
                     *reinterpret_cast<uint2*>(q1 + (pr * 4 + k) * 6400) = p2;
+                    if (GN && (k & 1)) __builtin_amdgcn_sched_barrier(0);     // (register budget of the fused-activation variant)
                 }
                 __builtin_amdgcn_sched_barrier(0);        // (one frame pair at a time: keeps the loader inside the register budget)
             }
@@ -275,6 +277,10 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         // A loader lane takes column w = lane >> 3 and quad j = lane & 7: eight lanes read one full row (conflict-free), and a
         // store instruction writes 8 points x 128 contiguous bytes -- full cache lines (the accumulator layout, lane = point with 16-byte
         // pieces of 32 rows per store, left the stores issue-bound at ~300 cycles each: tools/conv_stamps_w.py).
+        f32x4 pv1[8];                                     // finished rows of the previous tile's second frame pair, not yet stored (see drain)
+        float* pend_base = nullptr;
+        bool pend_ok = false;
+        const int pend_sh = kchunks >= 8 ? 0 : kchunks >= 4 ? 1 : 2;      // 8 stores over min(8, kchunks) steps
         auto epilogue = [&](int j, const unsigned char* xch) {
             int n0, w0, h0, f0, b;
             decode(j, n0, w0, h0, f0, b);
@@ -297,24 +303,27 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
             // (asm: the stores must not enter hipcc's vmcnt bookkeeping of this path -- see landed(); they retire in order with the
             // loads, so a later vmcnt(12 | 14) also waits for them), then the sums over the 8 columns (lane bits 3-5) and one
             // 32-byte row of GroupNorm partial-sum entry 2 pr + par of the tile per quad.
-            auto emit = [&](int pr, const f32x4 (&o)[8]) {
+            auto emit = [&](int pr, f32x4 (&o)[8]) {
                 const int f = f0 + 2 * pr + par;
                 float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+                const bool now = !pr || (p.dbg & 512);             // (512: A/B switch -- no deferred stores)
+                if (pr) pend_ok = f < p.F && !now;
                 if (f < p.F) {
                     const f32x4 bv = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbase) : f32x4{0.f, 0.f, 0.f, 0.f};
                     float* base = p.out + ((((long long)b * p.F + f) * p.H + h0) * p.W + w0 + col) * p.N + nbase;
+                    if (pr) pend_base = base;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = o[i][e] * descale + bv[e];
-                            gs[e] += v[e];
-                            gq[e] += v[e] * v[e];
+                            const float v = o[i][e] * descale + bv[e];
+                            o[i][e] = v;
+                            gs[e] += v;
+                            gq[e] += v * v;
                         }
                         // (s_nop: a VALU write to the data registers of a >64-bit store needs 2 wait states, and the hazard
                         // recogniser does not look into inline asm)
-                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(base + (long long)i * p.W * p.N), "v"(v) : "memory");
+                        if (now) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(base + (long long)i * p.W * p.N), "v"(o[i]) : "memory");
                     }
                 }
                 if (p.gn_part) {
@@ -333,17 +342,27 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                     }
                 }
             };
-            f32x4 o0[8], o1[8];
+            f32x4 o0[8];
             wg_barrier();                                  // E1: pair 0 is in LDS
             gather(o0);
             lds_done_barrier();                            // E2: the MFMA waves may overwrite it with pair 1
             wg_barrier();                                  // E3
-            gather(o1);
+            gather(pv1);
             lds_done_barrier();                            // E4: the buffer returns to the halo pipeline; the MFMA waves go on
             stamp();
             emit(0, o0);
             stamp();
-            emit(1, o1);
+            emit(1, pv1);
+        };
+        // Half of a tile's row stores (its second frame pair: 8 per lane) are NOT issued in the epilogue: every CU finishes its tile at
+        // the same moment and 32 MB of simultaneous stores run at the HBM write limit (~500 cycles per store instruction, 9 k cycles
+        // per tile in front of the next tile's first chunk).  They drain one or two per step behind the NEXT tile's halo production
+        // (all 16 do not fit the fused-activation variant's registers).
+        auto drain = [&](int slot) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if ((t >> pend_sh) == slot && pend_ok)
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(pend_base + (long long)t * p.W * p.N), "v"(pv1[t]) : "memory");
         };
         struct StepState { unsigned fok; int in0, in1; int kc; f32x4 cf[2]; };
         f32x4 ra[2][HFI], rb[2][HFI];                     // raw halo registers of two steps in flight (roles alternate: no copies)
@@ -364,12 +383,13 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         // iteration s: X = raw data of step s + 1 (requested one iteration ago); request step s + 2 into Y, finish X.  A tile is an
         // EVEN number of steps (conv3w_supported: K % 32 == 0), so the two register sets alternate without copies, the epilogue
         // exists once in the code and the buffer a tile leaves behind is always buffer 1.
-        auto body = [&](long long s, f32x4 (&X)[2][HFI], StepState& sx, f32x4 (&Y)[2][HFI], StepState& sy, int boff) {
+        auto body = [&](long long s, f32x4 (&X)[2][HFI], StepState& sx, f32x4 (&Y)[2][HFI], StepState& sy, int boff, int slot) {
             if (s + 2 < nsteps) { advance(); request(Y, sy); }
             stamp();
             if (s + 1 < nsteps) landed(X, sx.cf, s + 2 < nsteps);
             stamp();
             if (s + 1 < nsteps) finish(sx.kc, sx.fok, sx.in0, sx.in1, X, sx.cf, boff);   // the MFMA waves left that buffer at the previous barrier
+            drain(slot);
             stamp();
             lds_done_barrier();
             stamp();
@@ -377,13 +397,14 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         long long s = 0;
         for (int j = 0; j < ntiles; ++j) {
             for (int kc = 0; kc < kchunks; kc += 2) {
-                body(s, rb, sb, ra, sa, HBS);
-                body(s + 1, ra, sa, rb, sb, 0);
+                body(s, rb, sb, ra, sa, HBS, kc);
+                body(s + 1, ra, sa, rb, sb, 0, kc + 1);
                 s += 2;
             }
             if (!(p.dbg & 8)) epilogue(j, halo + HBS);
             stamp();
         }
+        for (int slot = 0; slot < 8; ++slot) drain(slot);       // the last tile
         __builtin_amdgcn_s_waitcnt(0);
         stamp_out();
         return;
