@@ -317,6 +317,10 @@ int launch_small_linear(const float* in, const float* W, const float* bias, floa
                         int in_act, int out_act, hipStream_t s);
 int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 int launch_cl_to_cf(const float* x_cl, float* x_cf, int BF, int C, long long HW, int F, hipStream_t s);  // debug taps
+// 1x1x1 convolution K = 64 -> N <= 8 channels, rows [M][K] -> per-frame channels-first out[M / HW][N][HW] (small.hip)
+bool conv1x1_rows_supported(int K, int N);
+int launch_conv1x1_rows(const float* x, const float* W, const float* bias, float* out, long long M, long long HW, int K, int N,
+                        hipStream_t s);
 int launch_cf_to_cl(const float* x_cf, float* x_cl, int BF, int C, long long HW, hipStream_t s);
 // nearest-neighbour x2 up-sampling of a channels-last image batch [BF][H][W][C] -> [BF][2H][2W][C]
 int launch_upsample2x_cl(const float* x, float* y, int BF, int H, int W, int C, hipStream_t s);

@@ -573,7 +573,10 @@ struct Runner {
         resnet("final_conv.0", x, X0, xc, dim, dim, Fz, false, Hl, Wl);
         tap("final_conv.0", Fz, dim, Hl, Wl);
         const PackedConv* pc = conv("final_conv.1.weight");
-        if (pc)
+        if (pc && conv1x1_rows_supported(dim, pc->N))
+            RUN(launch_conv1x1_rows(Fz, raw("final_conv.1.weight"), raw("final_conv.1.bias"), out, (long long)mb * F * Hl * Wl,
+                                    (long long)Hl * Wl, dim, pc->N, s));
+        else if (pc)
             RUN(run_conv(*pc, Fz, nullptr, dim, 0, raw("final_conv.1.bias"), nullptr, out, mb * F, F, Hl, Wl, Hl, Wl, nullptr,
                          nullptr, 1, 0, 0, s));
     }
@@ -659,6 +662,12 @@ int dpc_unet3d_load(dpc_unet3d_t h, const char* name_c, const float* w, const in
         auto pc = std::make_unique<PackedConv>();
         rc = pack_conv3d(*pc, w, (int)shape[0], (int)shape[1], kd, kh, kw, sh, sw, pd, ph, pw, s);
         h->conv[name] = std::move(pc);
+        if (!rc && name == "final_conv.1.weight") {          // reference layout too: the row-streaming final 1x1x1 conv (small.hip)
+            auto b = std::make_unique<DevBuf>();
+            if ((rc = b->alloc((size_t)numel * sizeof(float)))) return rc;
+            DPC_HIP(hipMemcpyAsync(b->p, w, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+            h->raw[name] = std::move(b);
+        }
     } else if (ends_with(name, "to_qkv.weight") || ends_with(name, "to_out.weight")) {
         auto pc = std::make_unique<PackedConv>();
         rc = pack_conv3d(*pc, w, (int)shape[0], (int)shape[1], 1, 1, 1, 1, 1, 0, 0, 0, s);   // Linear / Conv2d 1x1: [N][K]
