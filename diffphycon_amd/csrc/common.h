@@ -35,6 +35,16 @@ int fail(int code, const std::string& msg);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Remainder plane of the 2-way fp16 operand split: the packed pair (f16(x0 - h.lo), f16(x1 - h.hi)) for a packed f16 pair h, as ONE
+// v_fma_mix per element (f32 * 1.0 - f16 -> f16).  x - h is exact in fp32, so this rounds exactly as convert -> subtract -> convert
+// does, in a third of the VALU instructions.
+__device__ __forceinline__ unsigned f16_sub_pk(float x0, float x1, unsigned h) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(r) : "v"(x0), "v"(x1), "v"(h));
+    return r;
+}
+
 // ---------------------------------------------------------------- arithmetic modes (api.hip)
 // How fp32 products are evaluated, per op family: 0 = native fp32 MFMA, 1 = bf16x6 (exact 3-way bf16 split, 6 MFMAs),
 // 2 = f16x3 (2-way fp16 split, 3 MFMAs; default).  The process-wide setting (initialised from DPC_{CONV,IGEMM,ATTN,STEM}_MODE,

@@ -55,9 +55,8 @@ __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
     const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
     p1.x = cvt_pk_f16(x0, x1);
     p1.y = cvt_pk_f16(x2, x3);
-    const f16x2 a = __builtin_bit_cast(f16x2, p1.x), b = __builtin_bit_cast(f16x2, p1.y);
-    p2.x = cvt_pk_f16(x0 - (float)a.x, x1 - (float)a.y);
-    p2.y = cvt_pk_f16(x2 - (float)b.x, x3 - (float)b.y);
+    p2.x = f16_sub_pk(x0, x1, p1.x);
+    p2.y = f16_sub_pk(x2, x3, p1.y);
 }
 }  // namespace f3
 

@@ -22,12 +22,8 @@ __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, f
                                        f16x8 (&o)[2]) {
     uint4 a, b;
     a.x = cvt_pk(v0, v1); a.y = cvt_pk(v2, v3); a.z = cvt_pk(v4, v5); a.w = cvt_pk(v6, v7);
-    const f16x2 h0 = __builtin_bit_cast(f16x2, a.x), h1 = __builtin_bit_cast(f16x2, a.y);
-    const f16x2 h2 = __builtin_bit_cast(f16x2, a.z), h3_ = __builtin_bit_cast(f16x2, a.w);
-    b.x = cvt_pk(v0 - (float)h0.x, v1 - (float)h0.y);
-    b.y = cvt_pk(v2 - (float)h1.x, v3 - (float)h1.y);
-    b.z = cvt_pk(v4 - (float)h2.x, v5 - (float)h2.y);
-    b.w = cvt_pk(v6 - (float)h3_.x, v7 - (float)h3_.y);
+    // remainder plane: one v_fma_mix per element (common.h: f16_sub_pk)
+    b.x = f16_sub_pk(v0, v1, a.x); b.y = f16_sub_pk(v2, v3, a.y); b.z = f16_sub_pk(v4, v5, a.z); b.w = f16_sub_pk(v6, v7, a.w);
     o[0] = __builtin_bit_cast(f16x8, a);
     o[1] = __builtin_bit_cast(f16x8, b);
 }

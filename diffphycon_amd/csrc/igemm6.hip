@@ -237,9 +237,8 @@ __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
     const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
     p1.x = cvt_pk_f16(x0, x1);
     p1.y = cvt_pk_f16(x2, x3);
-    const f16x2_g a = __builtin_bit_cast(f16x2_g, p1.x), b = __builtin_bit_cast(f16x2_g, p1.y);
-    p2.x = cvt_pk_f16(x0 - (float)a.x, x1 - (float)a.y);
-    p2.y = cvt_pk_f16(x2 - (float)b.x, x3 - (float)b.y);
+    p2.x = f16_sub_pk(x0, x1, p1.x);
+    p2.y = f16_sub_pk(x2, x3, p1.y);
 }
 }  // namespace g3
 
@@ -546,8 +545,31 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     DPC_REQUIRE(p.kchunks == igemm_kchunks(p.C0 + p.C1), "igemm6: kchunks mismatch");
     DPC_REQUIRE(wp6 != nullptr, "igemm6: split weights missing");
     if (p.M == 0) return DPC_OK;
+    // Dead taps: a tap whose input row (or column) lies outside the image for EVERY output row multiplies zeros only -- on the
+    // 1 x 8 images of the Burgers U-Net's deepest level that is 6 of the 9 taps of every 3x3 convolution.  When the live taps are
+    // one contiguous range of the pack the launch simply covers that range (bit-identical sums: the skipped terms are exact zeros).
+    {
+        int lo = p.ntaps, hi = -1;
+        bool contiguous = true;
+        for (int t = 0; t < p.ntaps; ++t) {
+            bool hok = false, wok = false;
+            for (int o = 0; o < p.Ho && !hok; ++o) hok = (unsigned)(o * p.sh + p.tdh[t]) < (unsigned)p.Hi;
+            for (int o = 0; o < p.Wo && !wok; ++o) wok = (unsigned)(o * p.sw + p.tdw[t]) < (unsigned)p.Wi;
+            if (hok && wok) {
+                if (hi >= 0 && t != hi + 1) contiguous = false;
+                lo = std::min(lo, t);
+                hi = t;
+            }
+        }
+        if (contiguous && hi >= lo && (lo > 0 || hi < p.ntaps - 1)) {
+            const int n = hi - lo + 1;
+            for (int t = 0; t < n; ++t) { p.tdf[t] = p.tdf[lo + t]; p.tdh[t] = p.tdh[lo + t]; p.tdw[t] = p.tdw[lo + t]; }
+            wp6 = static_cast<const unsigned char*>(wp6) + (size_t)lo * p.kchunks * p.Npad * (igemm_mode_default() == 2 ? g3::WROW : 192);   // bytes per (iteration, n)
+            p.ntaps = n;
+        }
+    }
     const int mtiles = (int)((p.M + BM - 1) / BM);
-    const double flops = 2.0 * (double)p.M * p.N * (double)p.ntaps * (p.C0 + p.C1);
+    const double flops = 2.0 * (double)p.M * p.N * (double)p_in.ntaps * (p.C0 + p.C1);      // algorithmic: all taps of the operator
     const double bytes = 4.0 * ((double)p.M * (p.N + (p.resid ? p.N : 0)) + (double)p.BF * p.Hi * p.Wi * (p.C0 + p.C1) +
                                 (double)p.ntaps * (p.C0 + p.C1) * p.N);
     // few row tiles (deep U-Net levels: 2048 rows x 1024 channels in the Burgers POPC net): prefer 64-wide column tiles

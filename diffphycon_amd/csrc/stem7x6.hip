@@ -59,8 +59,7 @@ __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__built
 __device__ __forceinline__ void split2_2(float a, float b, unsigned& p1, unsigned& p2) {
     a = sat16(a); b = sat16(b);
     p1 = cvt_pk_f16(a, b);
-    const f16x2_s h = __builtin_bit_cast(f16x2_s, p1);
-    p2 = cvt_pk_f16(a - (float)h.x, b - (float)h.y);
+    p2 = f16_sub_pk(a, b, p1);
 }
 constexpr float SA = 16.f, SW = 4096.f, DESCALE = 1.f / 65536.f;
 }  // namespace s7

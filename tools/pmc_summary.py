@@ -19,8 +19,9 @@ from collections import defaultdict
 # kernel symbol -> bench.py / ProfScope class name
 CLASSES = [
     (r"conv3(x6|f3[bc]?)_kernel<128", "conv3x6_bn128"), (r"conv3(x6|f3[bc]?)_kernel<64", "conv3x6_bn64"),
+    (r"conv3w_kernel<(true|false), 128>", "conv3x6_bn128"), (r"conv3w_kernel<(true|false), 64>", "conv3x6_bn64"),
     (r"conv3h_kernel<128", "conv3h_bn128"), (r"conv3h_kernel<64", "conv3h_bn64"),
-    (r"igemm[63]?_kernel<128", "igemm_bn128"), (r"igemm[63]?_kernel<64", "igemm_bn64"),
+    (r"igemm[63]?_kernel<128", "igemm_bn128"), (r"igemm[63]?_kernel<64|conv1x1_rows_kernel", "igemm_bn64"),
     (r"stem7x6_kernel|stem_kernel", "stem_gather"), (r"tattn(_fused|6|3w?)_kernel", "temporal_attention_fused"),
     (r"lattn(3|6?_(ctx|out))_kernel", "linear_attention_fused"), (r"gn_(partial|finalize|finalize_fused|apply)_kernel", "groupnorm_silu"),
     (r"ln_stats_kernel", "ln_stats"), (r"ddpm_update_smoke_kernel", "ddpm_update"),
