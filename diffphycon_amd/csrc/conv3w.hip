@@ -26,6 +26,9 @@
 // are the same 22-bit f16x3 products with fp32 accumulation.  F(2,3) has transform constants 1 and 1/2 only: against an fp64
 // convolution the error stays inside the bound the direct kernels are tested to (tests/test_gpu_ops.py: 2e-6 sqrt(27 Cin)),
 // and the full-width U-Nets agree with the oracle to the same 2e-5 as before (tests/test_gpu_unet3d.py).
+// Perf attribution only (env DPC_CONV_DBG, Conv3hParams::dbg; results are INVALID except for 512): 2 the loader skips its global
+// loads, 32 the loader does nothing but the barriers, 4 every MFMA wave streams component 0's weights, 8 no epilogue, 512 the second
+// frame pair's stores are issued in the epilogue instead of deferred.
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:189-204).
 #include "common.h"
 #include "f3c.h"
@@ -104,9 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         // 216 MFMAs long: the per-chunk instruction count decides whether the matrix pipe waits.  Hence: raw buffer loads whose
         // out-of-range lanes read 0 (no exec-mask branches, 32-bit offsets), frame validity as wave-uniform branches, ONE fused
         // multiply-add from the raw input to the (pre-scaled) activation argument, exp2 / rcp hardware transcendentals.
-        if (p.dbg & 64) __builtin_amdgcn_s_setprio(0);
-        else if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(2);                    // (0 ... 3 measured: no difference)
         const int ltid = tid - 256;
         const bool two = ltid + 256 < ITEMS;              // threads 0..143 own a second item
         int hdst[2];

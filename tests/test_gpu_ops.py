@@ -61,6 +61,10 @@ CONV_CASES = [
     (1, 17, 8, 16, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (3, 4, 8, 8, 20, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 12, 24, 8, 72, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # ... with several 64-wide column tiles per plane tile
+    (2, 18, 8, 8, 64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 17, 8, 16, 32, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 4, 16, 16, 128, 384, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     # (1,3,3): the 2-D U-Net's 3x3 convolutions on the halo kernel, batch on the frame axis (any batch size, partial tiles)
     (1, 16, 16, 128, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (3, 1, 8, 64, 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
