@@ -174,6 +174,21 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
                 int rc = launch_pack_weights_w3(w_ref, wp, Cout, p.Npad, Cin, s);
                 if (rc) return rc;
                 q.wp = nullptr; q.wpw = wp;
+                // perf attribution only (tools/bench_conv.py): DPC_CONV_FAKE_GN=1 times the fused GroupNorm+SiLU loader on a
+                // constant coefficient table (y = x + 1); the result is then NOT the convolution of x
+                static const int fake_gn = [] { const char* e = getenv("DPC_CONV_FAKE_GN"); return e ? atoi(e) : 0; }();
+                if (fake_gn) {
+                    static float* tab = nullptr;
+                    static size_t cap = 0;
+                    const size_t need = (size_t)B * Cin * 7 * sizeof(float);
+                    if (need > cap) {
+                        if (tab) (void)hipFree(tab);
+                        DPC_HIP(hipMalloc(&tab, need));
+                        cap = need;
+                    }
+                    DPC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tab), 0x3f800000, need / 4, s));
+                    q.in_coef = tab;
+                }
                 return launch_conv3f3(q, s);
             }
             int rc = launch_pack_weights_f3(w_ref, wp, Cout, p.Npad, Cin, s);     // 64 B per (tap, chunk, n)
