@@ -70,20 +70,20 @@ __global__ void sinusoidal_kernel(const int64_t* __restrict__ t, const float* __
 
 // 1x1x1 convolution to a handful of output channels, written per-frame channels-first (the denoiser's final_conv.1,
 // video_diffusion_pytorch_conv3d.py:478-481: dim -> channels / out_dim).  As an implicit GEMM it pads 6 (or 2, 4, 1) output channels to a
-// 64-wide MFMA tile and ran at 1.2 TB/s; it is a row-streaming dot product: 256 rows are staged through LDS with coalesced 16-byte
+// 64-wide MFMA tile and ran at 1.2 TB/s; it is a row-streaming dot product: 64 rows per workgroup are staged through LDS with coalesced 16-byte
 // loads (row pitch K + 1 floats: conflict-free for the row-per-thread pass), each thread then reduces its row against the N weight
 // rows in plain fp32 (ascending k, exact products: no operand split in any arithmetic mode) and writes out[bf][n][hw].
-template <int K>
-__global__ __launch_bounds__(256) void conv1x1_rows_kernel(const float* __restrict__ x, const float* __restrict__ W,
+template <int K, int ROWS, int N>      // N compile-time: the weight rows become batched scalar loads, the N x K fused multiply-adds unroll
+__global__ __launch_bounds__(ROWS) void conv1x1_rows_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ out, long long M,
-                                                           long long HW, int N) {
-    __shared__ float tile[256 * (K + 1)];
+                                                           long long HW) {
+    __shared__ float tile[ROWS * (K + 1)];
     const int tid = threadIdx.x;
-    for (long long r0 = (long long)blockIdx.x * 256; r0 < M; r0 += (long long)gridDim.x * 256) {
+    for (long long r0 = (long long)blockIdx.x * ROWS; r0 < M; r0 += (long long)gridDim.x * ROWS) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < K / 4; ++i) {
-            const int idx = tid + 256 * i, row = idx / (K / 4), q = idx % (K / 4);
+            const int idx = tid + ROWS * i, row = idx / (K / 4), q = idx % (K / 4);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r0 + row < M) v = *reinterpret_cast<const f32x4*>(x + (r0 + row) * K + q * 4);
             float* d = tile + row * (K + 1) + q * 4;
@@ -92,21 +92,19 @@ __global__ __launch_bounds__(256) void conv1x1_rows_kernel(const float* __restri
         __syncthreads();
         const long long r = r0 + tid;
         if (r < M) {
-            float acc[8];
+            float acc[N];
 #pragma unroll
-            for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+            for (int n = 0; n < N; ++n) acc[n] = 0.f;
             const float* t = tile + tid * (K + 1);
-#pragma unroll 8
+#pragma unroll 16
             for (int k = 0; k < K; ++k) {
                 const float xv = t[k];
 #pragma unroll
-                for (int n = 0; n < 8; ++n)
-                    if (n < N) acc[n] = fmaf(xv, W[n * K + k], acc[n]);
+                for (int n = 0; n < N; ++n) acc[n] = fmaf(xv, W[n * K + k], acc[n]);
             }
             const long long bf = r / HW, hw = r - bf * HW;
 #pragma unroll
-            for (int n = 0; n < 8; ++n)
-                if (n < N) out[(bf * N + n) * HW + hw] = acc[n] + (bias ? bias[n] : 0.f);
+            for (int n = 0; n < N; ++n) out[(bf * N + n) * HW + hw] = acc[n] + (bias ? bias[n] : 0.f);
         }
     }
 }
@@ -118,8 +116,14 @@ int launch_conv1x1_rows(const float* x, const float* W, const float* bias, float
     DPC_REQUIRE(conv1x1_rows_supported(K, N), "conv1x1_rows: K == 64, N <= 8");
     if (M == 0) return DPC_OK;
     ProfScope prof(PROF_IGEMM64, 2.0 * (double)M * K * N, 4.0 * ((double)M * K + (double)M * N), s);
-    const int grid = (int)std::min<long long>((M + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(conv1x1_rows_kernel<64>, dim3(grid), dim3(256), 0, s, x, W, bias, out, M, HW, N);
+    // 64-row tiles of one wave each (16.6 KB of LDS: nine workgroups per CU overlap each other's load / compute phases; a 256-row
+    // tile left two workgroups per CU taking turns: 179 us for 268 MB)
+    const int grid = (int)std::min<long long>((M + 63) / 64, 256 * 36);
+#define DPC_ROWS_CASE(n) case n: hipLaunchKernelGGL((conv1x1_rows_kernel<64, 64, n>), dim3(grid), dim3(64), 0, s, x, W, bias, out, M, HW); break;
+    switch (N) {
+        DPC_ROWS_CASE(1) DPC_ROWS_CASE(2) DPC_ROWS_CASE(3) DPC_ROWS_CASE(4) DPC_ROWS_CASE(5) DPC_ROWS_CASE(6) DPC_ROWS_CASE(7) DPC_ROWS_CASE(8)
+    }
+#undef DPC_ROWS_CASE
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
