@@ -57,6 +57,57 @@ int launch_small_linear(const float* in, const float* W, const float* bias, floa
     return DPC_OK;
 }
 
+// The same op for up to 16 weight sets on ONE input in one launch (blockIdx.y = set): every ResnetBlock's time projection
+// mlp = Sequential(SiLU, Linear(dim * 4, 2 * dim_out)) (...conv3d.py:209-212) depends only on the time embedding, so a forward
+// computes all of them up front instead of 14 launches of ~4 us scattered through the network.  Per element the arithmetic is
+// that of small_linear_kernel (bit-identical results).
+template <int KR>
+__global__ __launch_bounds__(256) void small_linear_multi_kernel(const float* __restrict__ in, SmallLinearBatch d, int B, int K,
+                                                                 int in_act, int out_act, int nbb, int BB) {
+    const int set = blockIdx.y;
+    const int N = d.N[set];
+    const float* __restrict__ W = d.W[set];
+    const float* __restrict__ bias = d.bias[set];
+    float* __restrict__ out = d.out[set];
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)nbb * N) return;
+    const int n = (int)(wid % N), b0 = (int)(wid / N) * BB;
+    float w[KR];
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+        const int k = lane + 64 * j;
+        w[j] = k < K ? W[(long long)n * K + k] : 0.f;
+    }
+    const float bn = bias ? bias[n] : 0.f;
+    for (int b = b0; b < b0 + BB && b < B; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + 64 * j;
+            if (k < K) s += act_apply(in[(long long)b * K + k], in_act) * w[j];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) out[(long long)b * N + n] = act_apply(s + bn, out_act);
+    }
+}
+
+int launch_small_linear_multi(const float* in, const SmallLinearBatch& d, int B, int K, int in_act, int out_act, hipStream_t s) {
+    if (B == 0 || d.count == 0) return DPC_OK;
+    DPC_REQUIRE(d.count <= 16 && K <= 1024, "small_linear_multi: at most 16 sets, K <= 1024");
+    int nmax = 0;
+    double nsum = 0;
+    for (int i = 0; i < d.count; ++i) { nmax = std::max(nmax, d.N[i]); nsum += d.N[i]; }
+    ProfScope prof(PROF_SMALL, 2.0 * B * nsum * K, 4.0 * (nsum * K + (double)B * (nsum + K)), s);
+    const int bb = B >= 64 ? 16 : 1;
+    const int nbb = (B + bb - 1) / bb;
+    const dim3 grid((unsigned)(((long long)nbb * nmax + 3) / 4), (unsigned)d.count), blk(256);
+    if (K <= 256) hipLaunchKernelGGL(small_linear_multi_kernel<4>, grid, blk, 0, s, in, d, B, K, in_act, out_act, nbb, bb);
+    else hipLaunchKernelGGL(small_linear_multi_kernel<16>, grid, blk, 0, s, in, d, B, K, in_act, out_act, nbb, bb);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 // SinusoidalPosEmb (…conv3d.py:144-151): emb = t[:,None]*freqs[None,:]; cat(sin, cos)
 __global__ void sinusoidal_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs,
                                   float* __restrict__ out, int B, int half) {

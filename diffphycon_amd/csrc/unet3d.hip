@@ -296,15 +296,47 @@ struct Runner {
     }
 
     // ResnetBlock (…conv3d.py:206-230). dst == x0 (in place) is allowed when C1 == 0 and C0 == Cout.
+    // Every ResnetBlock's (scale, shift) = mlp(temb) (…conv3d.py:209-212, 222-225) depends on the time embedding only: all of them in
+    // one launch, in the order the traversal below consumes them (downs i.0, i.1; mid 1, 2; ups i.0, i.1).
+    std::vector<float*> ss_pre;
+    size_t ss_next = 0;
+    void time_projections(const std::vector<int>& dims, int nres) {
+        std::vector<std::pair<std::string, int>> blocks;
+        for (int i = 0; i < nres; ++i)
+            for (int j = 0; j < 2; ++j) blocks.push_back({"downs." + std::to_string(i) + "." + std::to_string(j), dims[i + 1]});
+        blocks.push_back({"mid_block1", dims[nres]});
+        blocks.push_back({"mid_block2", dims[nres]});
+        for (int i = 0; i < nres; ++i)
+            for (int j = 0; j < 2; ++j) blocks.push_back({"ups." + std::to_string(i) + "." + std::to_string(j), dims[nres - 1 - i]});
+        ss_pre.clear();
+        ss_next = 0;
+        if (blocks.size() > 16) return;                    // (deeper nets keep the per-block launches)
+        SmallLinearBatch d{};
+        for (const auto& bk : blocks) {
+            float* ss = ar.allocf((long long)mb * 2 * bk.second);
+            ss_pre.push_back(ss);
+            d.W[d.count] = raw(bk.first + ".mlp.1.weight");
+            d.bias[d.count] = raw(bk.first + ".mlp.1.bias");
+            d.out[d.count] = ss;
+            d.N[d.count] = 2 * bk.second;
+            ++d.count;
+        }
+        RUN(launch_small_linear_multi(temb, d, mb, h->cfg.dim * 4, 1, 0, s));
+    }
+
     void resnet(const std::string& p, const float* x0, const float* x1, int C0, int C1, int Cout, float* dst,
                 bool has_temb, int Hl, int Wl) {
         const long long P = (long long)mb * F * Hl * Wl;
         const size_t m = ar.mark();
         float* ss = nullptr;
         if (has_temb) {
-            ss = ar.allocf((long long)mb * 2 * Cout);
-            RUN(launch_small_linear(temb, raw(p + ".mlp.1.weight"), raw(p + ".mlp.1.bias"), ss, mb, h->cfg.dim * 4,
-                                    2 * Cout, 1, 0, s));
+            if (ss_next < ss_pre.size()) {                 // computed up front with all the other blocks' (time_projections)
+                ss = ss_pre[ss_next++];
+            } else {
+                ss = ar.allocf((long long)mb * 2 * Cout);
+                RUN(launch_small_linear(temb, raw(p + ".mlp.1.weight"), raw(p + ".mlp.1.bias"), ss, mb, h->cfg.dim * 4,
+                                        2 * Cout, 1, 0, s));
+            }
         }
         const bool same = (C1 == 0 && C0 == Cout);
         if (h->fused_gn && conv_mode_default() >= 1) {
@@ -482,6 +514,7 @@ struct Runner {
             if (!t.buf || t.floats != n) { t.buf.reset(new DevBuf()); if (t.buf->alloc(n * 4)) rc = DPC_ERR_HIP; t.floats = n; }
             if (!rc) RUN((hipMemcpyAsync(t.buf->p, temb, n * 4, hipMemcpyDeviceToDevice, s) == hipSuccess) ? 0 : DPC_ERR_HIP);
         }
+        time_projections(dims, nres);
         // stem (…conv3d.py:392, 503)
         float* X0 = ar.allocf(P0 * dim);
         {
