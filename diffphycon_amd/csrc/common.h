@@ -325,8 +325,8 @@ int launch_linear_attention(const float* qkv, float* out, int heads, long long i
 // out[b][n] = out_act( bias[n] + sum_k in_act(in[b][k]) * W[n][k] ),  act: 0 none, 1 SiLU, 2 GELU(erf)
 int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int B, int K, int N,
                         int in_act, int out_act, hipStream_t s);
-// the same for up to 16 (W, bias, out, N) sets sharing the input, one launch (small.hip)
-struct SmallLinearBatch { const float* W[16]; const float* bias[16]; float* out[16]; int N[16]; int count; };
+// the same for up to 32 (W, bias, out, N) sets sharing the input, one launch (small.hip)
+struct SmallLinearBatch { const float* W[32]; const float* bias[32]; float* out[32]; int N[32]; int count; };
 int launch_small_linear_multi(const float* in, const SmallLinearBatch& d, int B, int K, int in_act, int out_act, hipStream_t s);
 int launch_sinusoidal(const int64_t* t, const float* freqs, float* out, int B, int half, hipStream_t s);
 int launch_cl_to_cf(const float* x_cl, float* x_cf, int BF, int C, long long HW, int F, hipStream_t s);  // debug taps

@@ -57,9 +57,9 @@ int launch_small_linear(const float* in, const float* W, const float* bias, floa
     return DPC_OK;
 }
 
-// The same op for up to 16 weight sets on ONE input in one launch (blockIdx.y = set): every ResnetBlock's time projection
+// The same op for up to 32 weight sets on ONE input in one launch (blockIdx.y = set): every ResnetBlock's time projection
 // mlp = Sequential(SiLU, Linear(dim * 4, 2 * dim_out)) (...conv3d.py:209-212) depends only on the time embedding, so a forward
-// computes all of them up front instead of 14 launches of ~4 us scattered through the network.  Per element the arithmetic is
+// computes all of them up front instead of 14 (3-D nets) or 19-23 (Burgers nets) launches scattered through the network.  Per element the arithmetic is
 // that of small_linear_kernel (bit-identical results).
 template <int KR>
 __global__ __launch_bounds__(256) void small_linear_multi_kernel(const float* __restrict__ in, SmallLinearBatch d, int B, int K,
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void small_linear_multi_kernel(const float* __
 
 int launch_small_linear_multi(const float* in, const SmallLinearBatch& d, int B, int K, int in_act, int out_act, hipStream_t s) {
     if (B == 0 || d.count == 0) return DPC_OK;
-    DPC_REQUIRE(d.count <= 16 && K <= 1024, "small_linear_multi: at most 16 sets, K <= 1024");
+    DPC_REQUIRE(d.count <= 32 && K <= 1024, "small_linear_multi: at most 32 sets, K <= 1024");
     int nmax = 0;
     double nsum = 0;
     for (int i = 0; i < d.count; ++i) { nmax = std::max(nmax, d.N[i]); nsum += d.N[i]; }

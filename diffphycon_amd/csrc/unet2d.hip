@@ -147,12 +147,46 @@ struct Runner2D {
         ar.release(m);
     }
 
+    // Every ResnetBlock's (scale, shift) = mlp(temb) (unet.py:163-166, 176-179) depends on the time embedding only: all of them in one
+    // launch, in the order the traversal consumes them (downs i.0, i.1; mid 1, 2; ups i.0, i.1; final_res_block).
+    std::vector<float*> ss_pre;
+    size_t ss_next = 0;
+    void time_projections(const std::vector<int>& dims, int nres) {
+        std::vector<std::pair<std::string, int>> blocks;
+        for (int i = 0; i < nres; ++i)
+            for (int j = 0; j < 2; ++j) blocks.push_back({"downs." + std::to_string(i) + "." + std::to_string(j), dims[i]});
+        blocks.push_back({"mid_block1", dims[nres]});
+        blocks.push_back({"mid_block2", dims[nres]});
+        for (int i = 0; i < nres; ++i)
+            for (int j = 0; j < 2; ++j) blocks.push_back({"ups." + std::to_string(i) + "." + std::to_string(j), dims[nres - i]});
+        blocks.push_back({"final_res_block", dims[0]});
+        ss_pre.clear();
+        ss_next = 0;
+        if (blocks.size() > 32) return;                    // (deeper nets keep the per-block launches)
+        SmallLinearBatch d{};
+        for (const auto& bk : blocks) {
+            float* ss = ar.allocf((long long)mb * 2 * bk.second);
+            ss_pre.push_back(ss);
+            d.W[d.count] = raw(bk.first + ".mlp.1.weight");
+            d.bias[d.count] = raw(bk.first + ".mlp.1.bias");
+            d.out[d.count] = ss;
+            d.N[d.count] = 2 * bk.second;
+            ++d.count;
+        }
+        RUN(launch_small_linear_multi(temb, d, mb, h->cfg.dim * 4, 1, 0, s));
+    }
+
     // ResnetBlock (unet.py:157-191).  dst == x0 (in place) is allowed when C1 == 0 and C0 == Cout.
     void resnet(const std::string& p, const float* x0, const float* x1, int C0, int C1, int Cout, float* dst, int Hl, int Wl) {
         const long long P = (long long)mb * Hl * Wl;
         const size_t m = ar.mark();
-        float* ss = ar.allocf((long long)mb * 2 * Cout);
-        RUN(launch_small_linear(temb, raw(p + ".mlp.1.weight"), raw(p + ".mlp.1.bias"), ss, mb, h->cfg.dim * 4, 2 * Cout, 1, 0, s));
+        float* ss;
+        if (ss_next < ss_pre.size()) {                     // computed up front with all the other blocks' (time_projections)
+            ss = ss_pre[ss_next++];
+        } else {
+            ss = ar.allocf((long long)mb * 2 * Cout);
+            RUN(launch_small_linear(temb, raw(p + ".mlp.1.weight"), raw(p + ".mlp.1.bias"), ss, mb, h->cfg.dim * 4, 2 * Cout, 1, 0, s));
+        }
         float* h1 = ar.allocf(P * Cout);
         block(p + ".block1", x0, x1, C0, C1, Cout, h1, h1, nullptr, ss, Hl, Wl);
         const bool same = (C1 == 0 && C0 == Cout);
@@ -223,6 +257,7 @@ struct Runner2D {
             if (!t.buf || t.floats != n) { t.buf.reset(new DevBuf()); if (t.buf->alloc(n * 4)) rc = DPC_ERR_HIP; t.floats = n; }
             if (!rc) RUN((hipMemcpyAsync(t.buf->p, temb, n * 4, hipMemcpyDeviceToDevice, s) == hipSuccess) ? 0 : DPC_ERR_HIP);
         }
+        time_projections(dims, nres);
         // init_conv 7x7 (unet.py:333, 398) straight from the reference layout [B, C, H, W]
         float* X0 = ar.allocf(P0 * dim);
         {

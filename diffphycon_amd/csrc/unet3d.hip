@@ -310,7 +310,7 @@ struct Runner {
             for (int j = 0; j < 2; ++j) blocks.push_back({"ups." + std::to_string(i) + "." + std::to_string(j), dims[nres - 1 - i]});
         ss_pre.clear();
         ss_next = 0;
-        if (blocks.size() > 16) return;                    // (deeper nets keep the per-block launches)
+        if (blocks.size() > 32) return;                    // (deeper nets keep the per-block launches)
         SmallLinearBatch d{};
         for (const auto& bk : blocks) {
             float* ss = ar.allocf((long long)mb * 2 * bk.second);
