@@ -291,7 +291,7 @@ def timed_loop(ctx, step, steps, warmup, profile=True):
     return hi / steps, lo / steps, prof_all, prof, warm_ms
 
 
-def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_per_step):
+def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_per_step, traffic_scale=1.0):
     name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
     if d["flops"] > 0:
         achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
@@ -302,7 +302,10 @@ def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_
         achieved = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": pmc_traffic(name)}
-    roof["traffic_source"] = ("committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), not re-measured by this run"
+    if roof["traffic"] is not None:
+        roof["traffic"] *= traffic_scale
+    roof["traffic_source"] = ("committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: per launch of an 8-trajectory micro-batch, "
+                              f"scaled x{traffic_scale:g} to this run's launch size), not re-measured by this run"
                               if roof["traffic"] is not None else None)
     roof["kernel"], roof["launches"] = name, d["launches"]
     roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
@@ -508,7 +511,9 @@ def main():
     s128 = args.workload == "s128"
     frames, size = (64, 128) if s128 else (FRAMES, SIZE)
     B = args.batch or (8 if s128 else LOCAL_BATCH)
-    mbatch = args.micro_batch or (1 if s128 else 8)
+    # micro-batch 16: 4 forwards per net and step; the persistent conv kernel then walks 32 tiles per workgroup on the largest layers
+    # (8: 289.3 ms per step, 16: 286.1, 4: 311.1 on one box); the activation workspace is ~10 GB
+    mbatch = args.micro_batch or (1 if s128 else 16)
     unit_gflop = 14534.0 if s128 else UNIT_GFLOP
     gd, sd_cpu = build_models(device, mbatch, frames=frames, size=size)
     guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
@@ -534,7 +539,8 @@ def main():
     modes = gd.model_joint.modes
     out = None
     if rank == 0:
-        roof = roofline_of(prof, prof_all, modes, sec, args.steps, warm_ms, B * unit_gflop / 1e3)
+        roof = roofline_of(prof, prof_all, modes, sec, args.steps, warm_ms, B * unit_gflop / 1e3,
+                           traffic_scale=(min(mbatch, B) / 8.0) if not s128 else 1.0)
         cfg_name = ("S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames" if s128 else
                     "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames")
         out = {
