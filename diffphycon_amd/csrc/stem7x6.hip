@@ -68,9 +68,14 @@ typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_s __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool H3>
+// CS: channels per point slot.  8 (16-byte slots): a tap row is 4 MFMA k-steps (dw = 2 ks + hh).  4 (8-byte slots, C <= 4 -- the prior
+// denoiser's 2-channel stem, which filled 14 of 64 k-values of the 8-channel form): a tap row is 2 k-steps (dw = 4 ks + 2 hh, + 1), half
+// the MFMAs; an A fragment is two adjacent 8-byte slots (8-byte aligned: ds_read2_b64), rows are 128 B and not rotated.
+template <bool H3, int CS = 8>
 __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const unsigned char* __restrict__ wp6) {
     using namespace s7;
+    static_assert(CS == 8 || (CS == 4 && H3), "4-channel slots exist for the f16x3 form only");
+    constexpr int SLOTB = CS * 2, ROWB = SLOTS * SLOTB, PLANEB = HF * HH * ROWB, KS = CS / 2;     // (shadow the 8-channel constants of s7)
     constexpr int NP = H3 ? 2 : 3;                                // operand planes
     constexpr int WROWB = NP * 32;                                // packed weight bytes per (step, n)
     using frag_t = std::conditional_t<H3, f16x8_s, bf16x8_s>;
@@ -99,28 +104,34 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
         const int slot = q % SLOTS, row = q / SLOTS;              // row = pf * HH + ph
         const int pf = row / HH, ph = row % HH;
         const int f = f0 - 3 + pf, h = h0 - 3 + ph, w = w0 - 3 + slot;
-        float v[8];
+        float v[CS];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = 0.f;
+        for (int c = 0; c < CS; ++c) v[c] = 0.f;
         if (slot < HWL && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
             const float* src = p.x + (((long long)b * p.F + f) * p.Ctot + p.c_off) * HWin + (long long)h * p.W + w;
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < CS; ++c)
                 if (c < p.C) v[c] = src[(long long)c * HWin];
         }
-        u32x4 q1, q2, q3;
+        u32x4 q1 = {0, 0, 0, 0}, q2 = q1, q3 = q1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CS / 2; ++c) {
             unsigned a1, a2, a3 = 0;
             if constexpr (H3) split2_2(v[2 * c] * SA, v[2 * c + 1] * SA, a1, a2);
             else split3_2(v[2 * c], v[2 * c + 1], a1, a2, a3);
             q1[c] = a1; q2[c] = a2; q3[c] = a3;
         }
-        const int rslot = (slot + (((ph >> 1) & 1) << 3)) & 15;   // bank rotation of rows with odd (h >> 1)
-        unsigned char* dst = halo + row * ROWB + rslot * 16;
-        *reinterpret_cast<u32x4*>(dst) = q1;
-        *reinterpret_cast<u32x4*>(dst + PLANEB) = q2;
-        if constexpr (!H3) *reinterpret_cast<u32x4*>(dst + 2 * PLANEB) = q3;
+        if constexpr (CS == 8) {
+            const int rslot = (slot + (((ph >> 1) & 1) << 3)) & 15;   // bank rotation of rows with odd (h >> 1)
+            unsigned char* dst = halo + row * ROWB + rslot * 16;
+            *reinterpret_cast<u32x4*>(dst) = q1;
+            *reinterpret_cast<u32x4*>(dst + PLANEB) = q2;
+            if constexpr (!H3) *reinterpret_cast<u32x4*>(dst + 2 * PLANEB) = q3;
+        } else {
+            unsigned char* dst = halo + row * ROWB + slot * 8;
+            *reinterpret_cast<uint2*>(dst) = uint2{q1[0], q1[1]};
+            *reinterpret_cast<uint2*>(dst + PLANEB) = uint2{q2[0], q2[1]};
+        }
     }
 
     f32x16 acc[2];
@@ -149,16 +160,28 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
             const int row0 = ((wm * 2 + df) * HH + lh + dh) * ROWB;           // frame wm*2 (+ mt), halo row lh + dh
             const int rot = (((lh + dh) >> 1) & 1) << 3;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int step = (df * 7 + dh) * 4 + ks;
-                if (step + 1 < 196) ldw(step + 1, wx);
-                const int slot = (lw + 2 * ks + hh + rot) & 15;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int step = (df * 7 + dh) * KS + ks;
+                if (step + 1 < 49 * KS) ldw(step + 1, wx);
                 frag_t a[2][NP];
+                if constexpr (CS == 8) {
+                    const int slot = (lw + 2 * ks + hh + rot) & 15;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        a[mt][pl] = *reinterpret_cast<const frag_t*>(halo + pl * PLANEB + row0 + mt * (HH * ROWB) + slot * 16);
+                        for (int pl = 0; pl < NP; ++pl)
+                            a[mt][pl] = *reinterpret_cast<const frag_t*>(halo + pl * PLANEB + row0 + mt * (HH * ROWB) + slot * 16);
+                } else {
+                    const int off = (lw + 4 * ks + 2 * hh) * 8;               // two adjacent 4-channel slots: dw = 4 ks + 2 hh, + 1
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) {
+                            const unsigned char* src = halo + pl * PLANEB + row0 + mt * (HH * ROWB) + off;
+                            const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 8);
+                            a[mt][pl] = __builtin_bit_cast(frag_t, u32x4{lo.x, lo.y, hi.x, hi.y});
+                        }
+                }
                 if constexpr (H3) {
                     constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};                       // small terms first
 #pragma unroll
@@ -204,6 +227,11 @@ bool stem7x6_supported(int C, int k) { return k == 7 && C >= 1 && C <= 8; }
 size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }      // sized for 3 planes; f16x3 uses 64 of the 96 B
 
 static bool stem_h3() { return modes_current().stem != 1; }
+// 4-channel slots (half the MFMAs) for stems of at most 4 input channels in the f16x3 form; DPC_STEM_CS4=0 keeps the 8-channel form
+static bool stem_cs4(int C) {
+    static const int ok = [] { const char* e = getenv("DPC_STEM_CS4"); return e ? atoi(e) : 1; }();
+    return ok && C <= 4 && stem_h3();
+}
 
 int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     using namespace s7;
@@ -214,8 +242,8 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     const long long tiles = (long long)B * ((p.F + TF - 1) / TF) * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     const long long grid = tiles * (p.Npad / 64);
     DPC_REQUIRE(grid < (1ll << 31), "stem7x6: grid too large");
-    const bool h3 = stem_h3();
-    const size_t lds = (h3 ? 2 : 3) * (size_t)PLANEB;
+    const bool h3 = stem_h3(), cs4 = stem_cs4(p.C);
+    const size_t lds = cs4 ? (size_t)PLANEB : (h3 ? 2 : 3) * (size_t)PLANEB;       // (4-channel slots: 2 planes of half the size)
     ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * 343.0 * p.C, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
     static bool once = false;
     if (!once) {
@@ -223,23 +251,25 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
         DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PLANEB));
         once = true;
     }
-    if (h3) hipLaunchKernelGGL(stem7x6_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
+    if (cs4) hipLaunchKernelGGL((stem7x6_kernel<true, 4>), dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
+    else if (h3) hipLaunchKernelGGL(stem7x6_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
     else hipLaunchKernelGGL(stem7x6_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, p, (const unsigned char*)wp6);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
 
 // reference weight [N][C][7][7][7] fp32 -> [(df*7+dh)*4 + ks][Npad][3 planes][16] bf16, k = (dw - 2 ks) * 8 + c
-__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C, int h3,
+// (cs4: [(df*7+dh)*2 + ks][Npad][2 planes][16] fp16, k = (dw - 4 ks) * 4 + c)
+__global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C, int h3, int cs4,
                                     int* __restrict__ ovf) {
-    const long long total = 196ll * Npad * 16;
+    const long long total = (cs4 ? 98ll : 196ll) * Npad * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 16);
         long long r = i / 16;
         const int n = (int)(r % Npad);
         const int step = (int)(r / Npad);
-        const int ks = step & 3, tap = step >> 2, df = tap / 7, dh = tap % 7;
-        const int dw = 2 * ks + (kk >> 3), c = kk & 7;
+        const int ks = cs4 ? (step & 1) : (step & 3), tap = cs4 ? (step >> 1) : (step >> 2), df = tap / 7, dh = tap % 7;
+        const int dw = cs4 ? 4 * ks + (kk >> 2) : 2 * ks + (kk >> 3), c = cs4 ? (kk & 3) : (kk & 7);
         float v = 0.f;
         if (n < N && c < C && dw < 7) v = w[(((long long)n * C + c) * 7 + df) * 49 + dh * 7 + dw];
         if (h3) {
@@ -266,10 +296,11 @@ __global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short*
 }
 
 int launch_pack_stem7x6(const float* w, void* wp6, int N, int Npad, int C, hipStream_t s) {
-    const long long total = 196ll * Npad * 16;
+    const int cs4 = stem_cs4(C) ? 1 : 0;
+    const long long total = (cs4 ? 98ll : 196ll) * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_stem7x6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad, C,
-                       stem_h3() ? 1 : 0, f16x3_weight_overflow_flag());
+                       stem_h3() ? 1 : 0, cs4, f16x3_weight_overflow_flag());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
