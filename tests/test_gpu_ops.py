@@ -92,6 +92,31 @@ def test_conv3d_cl(case, dev, L):
     assert relerr(got, ref) < 2e-6 * (Ci * k[0] * k[1] * k[2]) ** 0.5 + 1e-6, relerr(got, ref)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_conv3d_winograd_random_shapes(seed, dev, L):
+    """Random shapes inside the Winograd kernel's domain (conv3w.hip: 3x3x3, H % 8 == 0, W % 8 == 0, Cin % 32 == 0, Cout % 64 == 0, F % 4 == 0
+    or F >= 16): several samples, fewer tiles than CUs as well as many, partial frame tiles, 1-4 column tiles, 2-8 channel chunks."""
+    import random
+    rnd = random.Random(1000 + seed)
+    B = rnd.choice([1, 2, 3])
+    Fr = rnd.choice([4, 8, 12, 16, 17, 18, 19, 20])
+    H, W = 8 * rnd.choice([1, 2, 3]), 8 * rnd.choice([1, 2, 4])
+    Ci, Co = 32 * rnd.choice([1, 2, 3, 4, 8]), 64 * rnd.choice([1, 2, 3, 4])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, Fr, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1).float()
+    xd, wd, bd = to_cl(x).to(dev), w.to(dev).contiguous(), b.to(dev)
+    out = torch.empty(to_cl(ref).shape, device=dev)
+    nb = L.lib().dpc_conv_workspace_bytes(Ci, Co, 27)
+    ws = L.workspace(nb, dev)
+    L.check(L.lib().dpc_conv3d_cl(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), B, Fr, H, W, Ci, Co, 3, 3, 3, 1, 1, 1, 1, 1, 1,
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    got = to_cf(out.cpu())
+    assert relerr(got, ref) < 2e-6 * (Ci * 27) ** 0.5 + 1e-6, ((B, Fr, H, W, Ci, Co), relerr(got, ref))
+
+
 @pytest.mark.parametrize("shape", [(2, 4, 8, 8, 16, 16), (1, 3, 16, 16, 128, 128), (1, 2, 4, 6, 64, 32)])
 def test_convtranspose3d_144(shape, dev, L):
     B, Fr, H, W, Ci, Co = shape
