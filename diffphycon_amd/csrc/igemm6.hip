@@ -577,7 +577,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     // 64-wide tiles at four workgroups per CU beat the 128-wide tile (two per CU) on every shape of both workloads
     // (smoke 31.4 -> 24.9 ms/step, Burgers 24.2 -> 22.0): DPC_IGEMM_WIDE=1 re-enables the wide tile for A/B runs
     static const int wide_ok = [] { const char* e = getenv("DPC_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
-    const bool wide = wide_ok && p.Npad % 128 == 0 && p.N > 64 && (long long)mtiles * (p.Npad / 128) >= 512;
+    const bool wide = wide_ok && !p.gn_raw && p.Npad % 128 == 0 && p.N > 64 && (long long)mtiles * (p.Npad / 128) >= 512;
     ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
     if (igemm_mode_default() == 2) {
         const size_t lds3 = 2 * (size_t)g3::BM * g3::RS;
