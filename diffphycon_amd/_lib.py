@@ -143,6 +143,25 @@ _SIGNATURES = {
     "dpc_pad_w_cl": (C.c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "dpc_fold_w_cl": (C.c_int, [_P, _P, _L, _I, _I, _I, _P]),
     "dpc_small_linear": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dpc_conv3_pack": (C.c_int, [_P] + [_I] * 10 + [C.c_char_p, C.POINTER(_P), _P]),
+    "dpc_conv3_run": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 6 + [_P, _P, _I, _I, _I, C.c_float, _P]),
+    "dpc_weight_range_check": (C.c_int, []),
+    "dpc_stem_pack": (C.c_int, [_P, _I, _I, _I, C.c_char_p, C.POINTER(_P), _P]),
+    "dpc_stem_free": (None, [_P]),
+    "dpc_stem_run": (C.c_int, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "dpc_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _L]),
+    "dpc_conv_wgrad_cl": (C.c_int, [_P, _P, _P] + [_I] * 19 + [C.c_float, _I, _P, _Z, _P]),
+    "dpc_colsum_workspace_bytes": (_Z, [_I]),
+    "dpc_colsum": (C.c_int, [_P, _P, _P, _P, _L, _I, C.c_float, _I, _P, _Z, _P]),
+    "dpc_gn_silu_bwd_params": (C.c_int, [_P] * 10 + [_I, _L, _I, _I, _P, _Z, _P]),
+    "dpc_attention_bwd_seq_workspace_bytes": (_Z, [_I, _I]),
+    "dpc_attention_bwd_seq": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _P, _P, _P, _I, _P, _Z, _P]),
+    "dpc_q_sample_smoke": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dpc_reduce_workspace_bytes": (_Z, []),
+    "dpc_mse_loss_grad": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, _P, _Z, _P]),
+    "dpc_l2_norm": (C.c_int, [_P, _L, C.c_float, _P, _P, _Z, _P]),
+    "dpc_adam_ema_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _I,
+                                    C.c_float, _P]),
     "dpc_burgers_fd": (C.c_int, [_P, _P, _P, _I, _I, _I, _D, _D, _D, _P]),
     "dpc_unet2d_create": (C.c_int, [C.POINTER(Unet2DCfg), C.POINTER(_P)]),
     "dpc_unet2d_destroy": (None, [_P]),

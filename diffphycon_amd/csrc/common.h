@@ -91,7 +91,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 enum ProfClass {
     PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
     PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_LATTN_FUSED, PROF_CONV3X6_64,
-    PROF_CONV3X6_128, PROF_NCLASS
+    PROF_CONV3X6_128, PROF_WGRAD, PROF_ATTN_BWD, PROF_TRAIN_MISC, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
@@ -296,7 +296,9 @@ int launch_gn_stats(const float* x, float* stats, int B, long long R, int C, int
 size_t gn_bwd_workspace_bytes(int B, int C);
 int launch_gn_silu_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                        const float* scale_shift, float* dx, float* dss, int B, long long R, int C, int groups, void* ws,
-                       hipStream_t s);
+                       hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr);
+// d gamma / d beta [C] of the same GroupNorm from the partial sums launch_gn_silu_bwd's first pass leaves in ws (train.hip)
+int launch_gn_param_grad(const void* ws, const float* scale_shift, float* dgamma, float* dbeta, int B, int C, int nchunk, hipStream_t s);
 // backward of the channel LayerNorm y = (x - mean) * rstd * g: dx (= or +=) per row
 int launch_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, long long rows, int C, int accum,
                   hipStream_t s);

@@ -510,7 +510,7 @@ size_t gn_bwd_workspace_bytes(int B, int C) {
 
 int launch_gn_silu_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
                        const float* scale_shift, float* dx, float* dss, int B, long long R, int C, int groups, void* ws,
-                       hipStream_t s) {
+                       hipStream_t s, float* dgamma, float* dbeta) {
     DPC_REQUIRE(C % 4 == 0 && C <= 1024 && (256 % (C / 4)) == 0, "groupnorm bwd: C/4 must divide 256");
     DPC_REQUIRE(groups >= 1 && C % groups == 0 && groups <= 1024, "groupnorm bwd: groups must divide C");
     if (B == 0 || R == 0) return DPC_OK;
@@ -524,6 +524,10 @@ int launch_gn_silu_bwd(const float* x, const float* dy, const float* stats, cons
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((B * groups + 3) / 4), dim3(256), 0, s, part, gamma, beta, scale_shift, coef,
                        dss, R, C, groups, nchunk, B);
     DPC_LAUNCH_CHECK();
+    if (dgamma || dbeta) {
+        DPC_REQUIRE(dgamma && dbeta, "groupnorm bwd: dgamma and dbeta go together");
+        if (int rc = launch_gn_param_grad(part, scale_shift, dgamma, dbeta, B, C, nchunk, s)) return rc;
+    }
     const int rpp = 256 / (C / 4);
     long long nblk = R / ((long long)rpp * 8);
     if (nblk < 1) nblk = 1;

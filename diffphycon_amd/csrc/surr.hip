@@ -508,6 +508,112 @@ int dpc_conv_pack(const float* w, int N, int K, int kh, int kw, int sh, int sw, 
 
 void dpc_conv_free(dpc_conv_t h) { delete h; }
 
+// 3-D form of the operator pair (training path of the space-time U-Net): any Conv3d of the net except the 7x7x7 stem, reference
+// weight layout [N][K][kd][kh][kw]; *inout != NULL re-packs into the existing handle (same shape: no allocation -- the weights
+// change every optimizer step).  No host synchronisation: the f16x3 weight-range flag is read by dpc_weight_range_check.
+int dpc_conv3_pack(const float* w, int N, int K, int kd, int kh, int kw, int sh, int sw, int pd, int ph, int pw, const char* mode,
+                   dpc_conv_t* inout, dpc_stream_t stream) {
+    DPC_REQUIRE(w && inout && N >= 1 && K >= 1 && kd >= 1 && kh >= 1 && kw >= 1, "conv3_pack: bad argument");
+    DPC_REQUIRE(K % 4 == 0, "conv3_pack: input channels must be a multiple of 4 (pad on the host)");
+    DPC_REQUIRE(kd * kh * kw <= 32, "conv3_pack: at most 32 taps (the stem has dpc_stem_pack)");
+    Modes md = modes_global();
+    if (mode && mode[0]) {
+        const std::string m(mode);
+        const int v = m == "f32" ? 0 : (m == "x6" ? 1 : (m == "f16x3" ? 2 : -1));
+        DPC_REQUIRE(v >= 0, "conv3_pack: unknown arithmetic mode '" + m + "'");
+        md.igemm = v;
+        md.conv = v;
+    }
+    std::unique_ptr<dpc_conv_s> fresh;
+    dpc_conv_s* h = *inout;
+    if (h) {
+        DPC_REQUIRE(h->pc.N == N && h->pc.K == K && h->pc.ntaps == kd * kh * kw && h->modes.conv == md.conv && h->modes.igemm == md.igemm,
+                    "conv3_pack: re-pack into a handle of another shape / mode");
+    } else {
+        fresh = std::make_unique<dpc_conv_s>();
+        h = fresh.get();
+        h->modes = md;
+    }
+    ModeScope scope(h->modes);
+    if (int rc = pack_conv3d(h->pc, w, N, K, kd, kh, kw, sh, sw, pd, ph, pw, (hipStream_t)stream)) return rc;
+    if (fresh) *inout = fresh.release();
+    return DPC_OK;
+}
+
+int dpc_conv3_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
+                  int B, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
+                  int par_b, float act_scale, dpc_stream_t stream) {
+    DPC_REQUIRE(h && a0 && out && B >= 1 && F >= 1, "conv3_run: null argument");
+    if (act_scale != 0.f) {
+        int e = 0;
+        DPC_REQUIRE(act_scale > 0.f && std::frexp(act_scale, &e) == 0.5f, "conv3_run: act_scale must be a power of two (or 0)");
+    }
+    ModeScope scope(h->modes);
+    return run_conv(h->pc, a0, a1, C0, C1, bias, resid, out, B * F, F, Hi, Wi, Ho, Wo, ln_stats, ln_gamma, out_mode, par_a, par_b,
+                    (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, act_scale, 0);
+}
+
+int dpc_weight_range_check(void) { return f16x3_weight_overflow_check("weight_range_check"); }
+
+// 7x7x7 stem (init_conv, ...conv3d.py:392) as an operator: x is the reference-layout state [B][F][ctot][H][W] (channel slice
+// [coff, coff + C)), out channels-last [B F H W][N].
+struct dpc_stem_s {
+    dpc::DevBuf wp, ktab, wp6;
+    int N = 0, C = 0, k = 0, npad = 0, kchunks = 0;
+    bool has6 = false;
+    dpc::Modes modes;
+};
+
+int dpc_stem_pack(const float* w, int N, int C, int k, const char* mode, dpc_stem_t* inout, dpc_stream_t stream) {
+    DPC_REQUIRE(w && inout && N >= 1 && C >= 1 && k >= 1 && (k & 1), "stem_pack: bad argument");
+    Modes md = modes_global();
+    if (mode && mode[0]) {
+        const std::string m(mode);
+        const int v = m == "f32" ? 0 : (m == "x6" ? 1 : (m == "f16x3" ? 2 : -1));
+        DPC_REQUIRE(v >= 0, "stem_pack: unknown arithmetic mode '" + m + "'");
+        md.stem = v;
+    }
+    std::unique_ptr<dpc_stem_s> fresh;
+    dpc_stem_s* h = *inout;
+    if (h) {
+        DPC_REQUIRE(h->N == N && h->C == C && h->k == k && h->modes.stem == md.stem, "stem_pack: re-pack into a handle of another shape");
+    } else {
+        fresh = std::make_unique<dpc_stem_s>();
+        h = fresh.get();
+        h->modes = md; h->N = N; h->C = C; h->k = k;
+    }
+    ModeScope scope(h->modes);
+    hipStream_t s = (hipStream_t)stream;
+    h->npad = (int)align_up(N, 64);
+    h->kchunks = igemm_kchunks(k * k * k * C);
+    int rc;
+    if ((rc = h->wp.alloc((size_t)h->kchunks * h->npad * 32 * sizeof(float)))) return rc;
+    if ((rc = h->ktab.alloc((size_t)h->kchunks * 32 * sizeof(int)))) return rc;
+    if ((rc = launch_pack_stem(w, h->wp.f(), (int*)h->ktab.p, N, h->npad, C, k, s))) return rc;
+    h->has6 = h->modes.stem != 0 && stem7x6_supported(C, k);
+    if (h->has6) {
+        if ((rc = h->wp6.alloc(stem7x6_packed_bytes(h->npad)))) return rc;
+        if ((rc = launch_pack_stem7x6(w, h->wp6.p, N, h->npad, C, s))) return rc;
+    }
+    if (fresh) *inout = fresh.release();
+    return DPC_OK;
+}
+
+void dpc_stem_free(dpc_stem_t h) { delete h; }
+
+int dpc_stem_run(dpc_stem_t h, const float* x, int x_channels_total, int x_channel_offset, const float* bias, float* out, int B, int F,
+                 int H, int W, dpc_stream_t stream) {
+    DPC_REQUIRE(h && x && out && B >= 1 && F >= 1, "stem_run: null argument");
+    DPC_REQUIRE(x_channel_offset >= 0 && x_channel_offset + h->C <= x_channels_total, "stem_run: bad channel slice");
+    ModeScope scope(h->modes);
+    StemParams sp{};
+    sp.x = x; sp.wp = h->wp.f(); sp.ktab = (const int*)h->ktab.p; sp.bias = bias; sp.out = out;
+    sp.BF = B * F; sp.F = F; sp.C = h->C; sp.H = H; sp.W = W; sp.Ctot = x_channels_total; sp.c_off = x_channel_offset;
+    sp.N = h->N; sp.Npad = h->npad; sp.kchunks = h->kchunks; sp.M = (long long)B * F * H * W;
+    if (h->has6) return launch_stem7x6(sp, h->wp6.p, (hipStream_t)stream);
+    return launch_stem(sp, (hipStream_t)stream);
+}
+
 int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
                  int BF, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
                  int par_b, float act_scale, int a0_stride, dpc_stream_t stream) {
@@ -542,6 +648,15 @@ int dpc_gn_silu_bwd(const float* x, const float* dy, const float* stats, const f
                 "gn_silu_bwd: bad argument / workspace too small");
     return launch_gn_silu_bwd(x, dy, stats, gamma, beta, scale_shift, dx, dss, B, R, C, groups,
                               reinterpret_cast<void*>(align_up((size_t)ws, 256)), (hipStream_t)stream);
+}
+
+int dpc_gn_silu_bwd_params(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                           const float* scale_shift, float* dx, float* dss, float* dgamma, float* dbeta, int B, int64_t R, int C,
+                           int groups, void* ws, size_t ws_bytes, dpc_stream_t stream) {
+    DPC_REQUIRE(x && dy && stats && gamma && beta && dx && dgamma && dbeta && ws && ws_bytes >= dpc_gn_workspace_bytes(B, C),
+                "gn_silu_bwd_params: bad argument / workspace too small");
+    return launch_gn_silu_bwd(x, dy, stats, gamma, beta, scale_shift, dx, dss, B, R, C, groups,
+                              reinterpret_cast<void*>(align_up((size_t)ws, 256)), (hipStream_t)stream, dgamma, dbeta);
 }
 
 int dpc_ln_stats(const float* x, float* stats, int64_t rows, int C, dpc_stream_t stream) {

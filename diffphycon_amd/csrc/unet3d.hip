@@ -195,6 +195,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = pc.wp.f(); q.bias = bias; q.out = out;
         q.B = BF / F; q.F = F; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = pc.kchunks;
         q.gn_part = gn_part; q.in_coef = in_coef;
+        q.act_scale = act_scale;
         if (conv_mode_default() == 2) {
             q.wp = reinterpret_cast<const float*>(pc.wp3.p);
             q.wpw = pc.wpw.p;

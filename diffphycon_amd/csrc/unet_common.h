@@ -12,6 +12,7 @@ struct DevBuf {
     size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n) {
+        if (p && bytes == n) return DPC_OK;          // re-pack of the same shape (training: the weights change every step)
         if (p) { (void)hipFree(p); p = nullptr; }
         bytes = n;
         DPC_HIP(hipMalloc(&p, n ? n : 4));

@@ -271,6 +271,76 @@ int dpc_absmax(const float* x, int64_t n, float* out, dpc_stream_t stream);
 int dpc_small_linear(const float* in, const float* W, const float* bias, float* out, int B, int K, int N, int in_act, int out_act,
                      dpc_stream_t stream);
 
+/* ------------------------------------------------------------------ training step of the smoke denoiser
+ * diffusion/diffusion_2d_smoke.py: q_sample :791-797, p_losses :809-831, Trainer.train :998-1054 (accelerator.backward :1025,
+ * clip_grad_norm_(1.0) :1027, Adam :912/:1035, EMA :920/:1043); the network is Unet3D_with_Conv3D
+ * (model/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py).  The backward pass is an explicit tape over these operators
+ * (diffphycon_amd/model/video_diffusion_pytorch/unet3d_train.py) -- no autograd graph, no torch convolution.
+ *
+ * dpc_conv3_pack / dpc_conv3_run: the 3-D form of dpc_conv_pack / dpc_conv_run: any Conv3d of the net but the stem (3x3x3 on
+ * the halo-tile kernels, 1x1x1, (1,4,4)/(1,2,2), the 2x2-tap parity classes of ConvTranspose3d with out_mode 2), reference weight
+ * layout [N][K][kd][kh][kw], mode "" | "f32" | "x6" | "f16x3".  *inout != NULL re-packs in place (no allocation, no host sync:
+ * the weights change every optimizer step); dpc_weight_range_check() reads the f16x3 weight-range flag once (DPC_ERR_STATE when a
+ * packed weight left the fp16 window since the last check).  Backward-data convolutions are the same operator on flipped /
+ * transposed weights with act_scale (power of two) placing the gradient inside the fp16 window, or in mode "x6".
+ * dpc_stem_pack / dpc_stem_run: the 7x7x7 init_conv (:392) on the reference-layout state [B][F][ctot][H][W]. */
+int dpc_conv3_pack(const float* w, int N, int K, int kd, int kh, int kw, int sh, int sw, int pd, int ph, int pw, const char* mode,
+                   dpc_conv_t* inout, dpc_stream_t stream);
+int dpc_conv3_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
+                  int B, int F, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
+                  int par_b, float act_scale, dpc_stream_t stream);
+int dpc_weight_range_check(void);
+typedef struct dpc_stem_s* dpc_stem_t;
+int dpc_stem_pack(const float* w, int N, int C, int k, const char* mode, dpc_stem_t* inout, dpc_stream_t stream);
+void dpc_stem_free(dpc_stem_t h);
+int dpc_stem_run(dpc_stem_t h, const float* x, int x_channels_total, int x_channel_offset, const float* bias, float* out, int B, int F,
+                 int H, int W, dpc_stream_t stream);
+/* Convolution weight gradient (what accelerator.backward :1025 leaves in Conv3d.weight.grad): x channels-last [B,F,Hi,Wi,C],
+ * dy channels-last [B,F,Ho,Wo,N], dw in the reference layout [N][dw_ctot][kf][kh][kw], channel slice [dw_coff, dw_coff + c_valid)
+ * (a concatenated input = one call per source; c_valid < C: zero-padded input channels, 0 = C), dw = (accumulate ? dw : 0) +
+ * scale * sum_p dy[p][n] x[p + tap][c].  C must divide or be a multiple of 32.  ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1)
+ * (weight [Cin][Cout][1][4][4]): call with x = the transposed conv's OUTPUT gradient and dy = its input, geometry of the
+ * (1,4,4)/(1,2,2)/(0,1,1) convolution.  Exact fp32 products (native fp32 MFMA), fixed summation order. */
+size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows /* B * F * Ho */);
+int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, int Hi, int Wi, int C, int Ho, int Wo, int N, int kf,
+                      int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
+                      int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream);
+/* out[c] = (accumulate ? out[c] : 0) + scale * sum_r dy[r][c] (x NULL: bias gradients) or
+ * scale * sum_r dy[r][c] (x[r][c] - mean_r) rstd_r (channel-LayerNorm gamma gradient :195-204, ln_stats [rows][2]); fp64 partials */
+size_t dpc_colsum_workspace_bytes(int C);
+int dpc_colsum(const float* dy, const float* x, const float* ln_stats, float* out, int64_t rows, int C, float scale, int accumulate,
+               void* ws, size_t ws_bytes, dpc_stream_t stream);
+/* dpc_gn_silu_bwd + the affine gradients d gamma, d beta [C] of the GroupNorm (Block.norm :193) */
+int dpc_gn_silu_bwd_params(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                           const float* scale_shift, float* dx, float* dss, float* dgamma, float* dbeta, int B,
+                           int64_t rows_per_sample, int C, int groups, void* ws, size_t ws_bytes, dpc_stream_t stream);
+/* Backward of dpc_attention_core for sequences of L <= 64 tokens with the same addressing, rotary tables and bias
+ * (Attention.forward :293-352: q scale, rotary on q and k, + pos_bias, softmax, PV): dqkv [rows][3*heads*32] given dout
+ * [rows][heads*32]; dbias [heads][L][L] (NULL: skipped) = (accumulate_dbias ? dbias : 0) + sum over sequences of dS. */
+size_t dpc_attention_bwd_seq_workspace_bytes(int heads, int L);
+int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, float* dbias, int heads, int L, int64_t n_seq,
+                          int64_t seq_inner, int64_t seq_outer_stride_rows, int64_t seq_inner_stride_rows, int64_t token_stride_rows,
+                          const float* rot_cos, const float* rot_sin, const float* bias, int accumulate_dbias, void* ws, size_t ws_bytes,
+                          dpc_stream_t stream);
+/* p_losses :811-816: state = sqrt_ac[t_b] x0 + sqrt_1mac[t_b] noise with state[:, 0, 0] = x0[:, 0, 0]; target = noise with
+ * [:, 0, 0] = 0.  x0 = channel slice of a [B][F][ctot][H][W] tensor (Trainer.train :1018-1019 trains the w model on [:, :, 3:5]). */
+int dpc_q_sample_smoke(const float* x0, int x_channels_total, int x_channel_offset, const float* noise, const int64_t* t,
+                       const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod, float* state, float* target, int B,
+                       int F, int C, int H, int W, dpc_stream_t stream);
+/* loss[0] = mean (out - target)^2 (F.mse_loss :827); dout (NULL: skipped) = grad_scale * 2 (out - target) / n */
+size_t dpc_reduce_workspace_bytes(void);
+int dpc_mse_loss_grad(const float* out, const float* target, float* dout, float* loss, int64_t n, float grad_scale, void* ws,
+                      size_t ws_bytes, dpc_stream_t stream);
+/* out[0] = scale * ||x||_2 (clip_grad_norm_'s total norm :1027 over the flat gradient buffer), fp64 partials, fixed order */
+int dpc_l2_norm(const float* x, int64_t n, float scale, float* out, void* ws, size_t ws_bytes, dpc_stream_t stream);
+/* One optimizer step on flat fp32 buffers (Trainer.train :1027-1043): g <- g * grad_inv_scale * min(1, max_norm / (total_norm[0] +
+ * 1e-6)) (total_norm NULL or max_norm <= 0: no clipping), torch.optim.Adam's update with its association (exp_avg.lerp_,
+ * exp_avg_sq.mul_.addcmul_, param.addcdiv_(exp_avg, sqrt(v) / sqrt(1 - beta2^step) + eps, -lr / (1 - beta1^step))), then the EMA
+ * of ema-pytorch 0.7.3 on `ema`: ema_mode 0 none | 1 copy | 2 lerp with ema_weight = 1 - decay | 3 copy then lerp. */
+int dpc_adam_ema_step(float* w, const float* g, float* m, float* v, float* ema, int64_t n, const float* total_norm, float max_norm,
+                      float grad_inv_scale, float lr, float beta1, float beta2, float eps, int step, int ema_mode, float ema_weight,
+                      dpc_stream_t stream);
+
 /* ------------------------------------------------------------------ Burgers finite-difference solver
  * Replaces dataset/apps/generate_burgers.py:207-299 burgers_numeric_solve_free (fp32, explicit Euler).
  * u0 [N,nx], f [N,num_t,nx] -> traj [N,num_t+1,nx]. */

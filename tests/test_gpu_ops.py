@@ -88,9 +88,9 @@ def test_conv3d_cl(case, dev, L):
     L.check(L.lib().dpc_conv3d_cl(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), B, Fr, H, W, Ci, Co, *k, *s, *p,
                                   C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
     got = to_cf(out.cpu())
-    print(f"CONVERR {case} {relerr(got, ref):.3e}")
-    # fp32 MFMA accumulation over K = Cin*taps terms vs an fp64 reference
-    assert relerr(got, ref) < 2e-6 * (Ci * k[0] * k[1] * k[2]) ** 0.5 + 1e-6, relerr(got, ref)
+    # split operands (22 bits) + fp32 accumulation over K = Cin * taps terms vs an fp64 reference: measured 1.3e-7 .. 9.5e-7 of the
+    # output range over these cases (profiles/r03_a_conv_errors.log); 3e-6 = 3 x the largest, inside SURVEY 8d's per-block 1e-5
+    assert relerr(got, ref) < 3e-6, relerr(got, ref)
 
 
 @pytest.mark.parametrize("seed", range(10))
