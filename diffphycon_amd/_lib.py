@@ -156,6 +156,7 @@ _SIGNATURES = {
     "dpc_gn_silu_bwd_params": (C.c_int, [_P] * 10 + [_I, _L, _I, _I, _P, _Z, _P]),
     "dpc_attention_bwd_seq_workspace_bytes": (_Z, [_I, _I]),
     "dpc_attention_bwd_seq": (C.c_int, [_P, _P, _P, _P, _I, _I, _L, _L, _L, _L, _L, _P, _P, _P, _I, _P, _Z, _P]),
+    "dpc_small_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpc_q_sample_smoke": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpc_reduce_workspace_bytes": (_Z, []),
     "dpc_mse_loss_grad": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, _P, _Z, _P]),

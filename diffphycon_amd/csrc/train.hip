@@ -548,6 +548,47 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ w, co
     }
 }
 
+// Backward of dpc_small_linear (out = bias + act(in) W^T; time_mlp ...conv3d.py:404-409, ResnetBlock.mlp :209-212), B <= a few
+// hundred rows: one thread per output element, the batch / feature loop inside (fixed order).
+//   dW[n][k] = sum_b dy[b][n] act(x[b][k]);  db[n] = sum_b dy[b][n];  dx[b][k] (+)= act'(x[b][k]) sum_n dy[b][n] W[n][k]
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == 1) return v / (1.0f + expf(-v));
+    if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    return v;
+}
+__device__ __forceinline__ float act_grad(float v, int act) {
+    if (act == 1) {
+        const float sg = 1.0f / (1.0f + expf(-v));
+        return sg * (1.0f + v * (1.0f - sg));
+    }
+    if (act == 2) return 0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * expf(-0.5f * v * v) * 0.3989422804014327f;
+    return 1.0f;
+}
+__global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ W, float* __restrict__ dx, float* __restrict__ dW,
+                                                              float* __restrict__ db, int B, int K, int N, int in_act, int accum_dx) {
+    const long long nW = (long long)N * K, nX = dx ? (long long)B * K : 0, nB = db ? N : 0;
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < nW) {
+        const int n = (int)(i / K), k = (int)(i % K);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(long long)b * N + n] * act_fwd(x[(long long)b * K + k], in_act);
+        dW[i] = s;
+    } else if (i < nW + nX) {
+        const long long j = i - nW;
+        const int b = (int)(j / K), k = (int)(j % K);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dy[(long long)b * N + n] * W[(long long)n * K + k];
+        s *= act_grad(x[j], in_act);
+        dx[j] = accum_dx ? dx[j] + s : s;
+    } else if (i < nW + nX + nB) {
+        const int n = (int)(i - nW - nX);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(long long)b * N + n];
+        db[n] = s;
+    }
+}
+
 static inline unsigned grid1d(long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 256 * 8); }
 
 }  // namespace dpc
@@ -701,6 +742,18 @@ int dpc_l2_norm(const float* x, int64_t n, float scale, float* out, void* ws, si
     hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, x, part, (long long)n);
     DPC_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, part, nblk, (double)scale, 1, out);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
+int dpc_small_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int B, int K, int N,
+                         int in_act, int accumulate_dx, dpc_stream_t stream) {
+    DPC_REQUIRE(dy && x && W && dW && B >= 1 && K >= 1 && N >= 1 && in_act >= 0 && in_act <= 2, "small_linear_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)N * K + (dx ? (long long)B * K : 0) + (db ? N : 0);
+    ProfScope prof(PROF_TRAIN_MISC, 0, 0, s);
+    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, x, W, dx, dW, db, B, K, N, in_act,
+                       accumulate_dx);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

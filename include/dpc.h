@@ -322,6 +322,10 @@ int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, floa
                           int64_t seq_inner, int64_t seq_outer_stride_rows, int64_t seq_inner_stride_rows, int64_t token_stride_rows,
                           const float* rot_cos, const float* rot_sin, const float* bias, int accumulate_dbias, void* ws, size_t ws_bytes,
                           dpc_stream_t stream);
+/* Backward of dpc_small_linear (out = bias + in_act(x) W^T): dW [N][K], db [N] (NULL: skipped) and dx [B][K] (NULL: skipped;
+ * gradient w.r.t. the PRE-activation input, accumulate_dx != 0: +=) given dy [B][N] */
+int dpc_small_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int B, int K, int N,
+                         int in_act, int accumulate_dx, dpc_stream_t stream);
 /* p_losses :811-816: state = sqrt_ac[t_b] x0 + sqrt_1mac[t_b] noise with state[:, 0, 0] = x0[:, 0, 0]; target = noise with
  * [:, 0, 0] = 0.  x0 = channel slice of a [B][F][ctot][H][W] tensor (Trainer.train :1018-1019 trains the w model on [:, :, 3:5]). */
 int dpc_q_sample_smoke(const float* x0, int x_channels_total, int x_channel_offset, const float* noise, const int64_t* t,
