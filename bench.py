@@ -382,6 +382,66 @@ def run_burgers(ctx, args, t_start, batch=256, with_cpu=True, exact=True):
     return out
 
 
+TRAIN_FWD_GFLOP = 897.3               # one joint-denoiser forward of a 64x64x32 sample (half of UNIT_GFLOP's pair,
+                                      # stem included); a training step costs ~3x (forward + backward-data + weight gradient)
+
+
+def run_train(ctx, args, t_start, batch=16, with_cpu=True):
+    """one optimizer step of the smoke joint denoiser (train_2d_smoke.py: Unet3D dim 64, mults (1,2,4), 6
+    channels, 64x64x32, lr 1e-3) = q_sample + p_losses forward + hand-written backward + gradient all-reduce (N > 1) + gradient
+    norm + fused clip/Adam/EMA, batch 16 per GPU (Trainer's default train_batch_size)."""
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, Trainer
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    torch.manual_seed(0)
+    m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6)
+    sd_cpu = {k: v.clone() for k, v in m.state_dict().items()}
+    gd = GaussianDiffusion(m, image_size=SIZE, frames=FRAMES, timesteps=1000, sampling_timesteps=250, loss_type="l2",
+                           objective="pred_noise", device=ctx.device)
+    bwd_mode = os.environ.get("DPC_TRAIN_BWD_MODE", "x6")
+    loss_scale = float(os.environ.get("DPC_TRAIN_LOSS_SCALE", "1"))
+    tr = Trainer(gd, "Smoke", None, train_batch_size=batch * ctx.world, train_lr=1e-3, is_w_model=False, bwd_mode=bwd_mode,
+                 loss_scale=loss_scale)
+    g = torch.Generator().manual_seed(100 + ctx.rank)
+    state = (torch.randn(batch, FRAMES, 6, SIZE, SIZE, generator=g) * 0.5).to(ctx.device)
+    losses = []
+
+    def step():
+        losses.append(tr.train_step([state]))
+    sec, sec_min, prof_all, prof, warm_ms = timed_loop(ctx, step, args.steps, max(args.warmup, 1))
+    first, last = float(losses[0].item()), float(losses[-1].item())
+    assert torch.isfinite(tr._t.w).all() and last == last, "non-finite weights / loss after the timed steps"
+    out = {"metric": "training samples/sec, 2D smoke 64x64x32 joint denoiser (p_losses forward + backward + clip + Adam + EMA)",
+           "value": ctx.world * batch / sec, "unit": "samples/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "arithmetic": f"forward {gd.model.modes if hasattr(gd.model, 'modes') else ''}; backward-data convolutions {bwd_mode}"
+                         f" (loss scale {loss_scale:g}); weight gradients exact fp32 products on the native fp32 MFMA",
+           "loss_first_last": [first, last],
+           "config": {"workload": "S64 training step (SURVEY 8 f-4; scripts/smoke_train_joint.sh): Unet3D(dim 64, mults 1-2-4, 6 "
+                                  f"channels) on 64x64 x 32 frames, batch={batch} per GPU, one optimizer step per bench step",
+                      "global_batch": ctx.world * batch, "parallelism": f"data-parallel x{ctx.world} (one flat-gradient all-reduce)"}}
+    if ctx.rank == 0:
+        out["roofline"] = roofline_of(prof, prof_all, "", sec, args.steps, warm_ms, 3 * batch * TRAIN_FWD_GFLOP / 1e3)
+    ctx.log(t_start, f"train: {sec * 1e3:.1f} ms per optimizer step, loss {first:.4f} -> {last:.4f}")
+    out["cpu_baseline"] = None
+    if with_cpu and ctx.rank == 0 and ctx.world == 1:
+        from oracle import train_smoke as TS
+        from oracle import unet3d as O
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
+        sched = TS.schedule(1000)
+        x0 = state[:1].cpu()
+        noise = torch.randn(x0.shape, generator=g)
+        t0 = time.perf_counter()
+        TS.loss_and_grads(sd_cpu, cfg, sched, x0, torch.tensor([500]), noise)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+                               "sample": f"ONE p_losses forward + torch-autograd backward of the CPU oracle at B=1, 64x64x32, fp32 on "
+                                         f"{cores} threads ({dt:.1f} s; no optimizer step)"}
+    return out
+
+
 def run_smoke_evaluator(ctx, B=64, T=256):
     """Post-sampling PDE evaluator: B rollouts x T frames in one launch, as multi_evaluate consumes them."""
     import numpy as np
@@ -427,7 +487,7 @@ def self_launch(args, argv):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128"],
+    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128", "train"],
                     help="smoke = BASELINE.json's headline metric S64 (default); burgers = configs[1]; s128 = configs[4] shape "
                          "(128x128x64 frames; builder-side line, batch 8 per GPU by default)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -500,6 +560,16 @@ def main():
         if rank == 0:
             out.update({"warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                         "data": "synthetic", "world_size_seen_by_rccl": seen_world, "launcher": launcher})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "train":
+        out = run_train(ctx, args, t_start, batch=args.batch or 16, with_cpu=not args.no_cpu_baseline)
+        if rank == 0:
+            out.update({"world_size_seen_by_rccl": seen_world, "launcher": launcher})
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()

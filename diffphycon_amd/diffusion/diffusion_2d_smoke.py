@@ -311,31 +311,261 @@ class GaussianDiffusion(nn.Module):
                          device=device)
 
 
-class Trainer(object):
-    """Checkpoint READER only (training is out of scope): `Trainer(diffusion, dataset, dataset_path,
-    results_path=...).load(milestone)` as used by inference_2d_smoke.py:70-77,102-109; file format of
-    diffusion_2d_smoke.py:942-954 (`torch.save({'step','model','opt','ema','scaler'})`)."""
+def _gd_trainable(self, bwd_mode="x6", loss_scale=1.0):
+    """The training view of this diffusion's denoiser (model/video_diffusion_pytorch/unet3d_train.py), built once."""
+    t = getattr(self, "_trainable", None)
+    if t is None or t.ctx.bwd_mode != bwd_mode or t.loss_scale != float(loss_scale):
+        from ..model.video_diffusion_pytorch.unet3d_train import TrainableUnet3D
+        assert not self.eval_2ddpm, "training runs on a single-model GaussianDiffusion (train_2d_smoke.py:54-61)"
+        dev = self.betas.device
+        if dev.type != "cuda":
+            raise RuntimeError("p_losses needs the diffusion on the GPU: libdpc has no CPU path")
+        t = TrainableUnet3D(self.model, dev, bwd_mode=bwd_mode, loss_scale=loss_scale)
+        self._trainable = t
+    return t
 
-    def __init__(self, diffusion_model, dataset=None, dataset_path=None, *, results_path="./results", amp=False,
-                 **unused):
+
+def _gd_q_sample(self, x_start, t, noise=None):
+    """(:791-797)"""
+    noise = default(noise, lambda: torch.randn_like(x_start))
+    return (extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start +
+            extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+
+def _gd_p_losses(self, state_start, t, noise=None):
+    """p_losses (:809-831), loss_type 'l2', objective 'pred_noise': returns the loss (a device tensor of one element) and --
+    what the reference leaves to `loss.backward()` -- fills the flat gradient buffer of `self.trainable()` in the same pass."""
+    if self.loss_type != "l2":
+        raise NotImplementedError("the training path implements the 'l2' loss the train scripts use (train_2d_smoke.py:59)")
+    T = self.trainable()
+    noise = default(noise, lambda: torch.randn_like(state_start))
+    return T.p_losses(state_start.float().contiguous(), t.long().contiguous(), noise.float().contiguous(),
+                      self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+
+
+def _gd_forward(self, state, *args, **kwargs):
+    """(:833-839)"""
+    b = state.shape[0]
+    t = torch.randint(0, self.num_timesteps, (b,), device=state.device).long()
+    return self.p_losses(state, t, *args, **kwargs)
+
+
+GaussianDiffusion.trainable = _gd_trainable
+GaussianDiffusion.q_sample = _gd_q_sample
+GaussianDiffusion.p_losses = _gd_p_losses
+GaussianDiffusion.forward = _gd_forward
+
+
+class _EmaSchedule:
+    """When and how `EMA.update()` of ema-pytorch 0.7.3 (environment.yaml:41; Trainer :920 passes beta = ema_decay,
+    update_every = ema_update_every; the package defaults update_after_step 100, inv_gamma 1, power 2/3, min_value 0) touches
+    the averaged weights: every `update_every` calls -- a plain copy while step <= update_after_step, afterwards
+    ema.lerp_(online, 1 - decay) with decay = clamp(1 - (1 + epoch) ** -power, min_value, beta), epoch = step - update_after_step - 1
+    (0 while epoch <= 0).  Restated from the published algorithm: the wheel is not available offline (unpinned)."""
+
+    def __init__(self, beta=0.995, update_every=10, update_after_step=100, inv_gamma=1.0, power=2.0 / 3.0, min_value=0.0):
+        self.beta, self.update_every, self.update_after_step = beta, update_every, update_after_step
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.step, self.initted = 0, False
+
+    def decay(self):
+        epoch = max(self.step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        return min(max(1 - (1 + epoch / self.inv_gamma) ** -self.power, self.min_value), self.beta)
+
+    def next(self):
+        """-> (ema_mode, weight) of dpc_adam_ema_step for this update() call (0 none | 1 copy | 2 lerp | 3 copy then lerp)."""
+        step = self.step
+        self.step += 1
+        if step % self.update_every != 0:
+            return 0, 0.0
+        if step <= self.update_after_step:
+            return 1, 0.0
+        mode = 2 if self.initted else 3
+        self.initted = True
+        return mode, 1.0 - self.decay()
+
+
+class Trainer(object):
+    """`Trainer` of diffusion_2d_smoke.py:843-1054 on libdpc: same constructor keywords, `train()`, `save()` / `load()` file
+    format (:942-985: torch.save({'step', 'model', 'opt', 'ema', 'scaler'})).  One optimizer step = p_losses forward + the
+    hand-written backward (model/video_diffusion_pytorch/unet3d_train.py), ONE all-reduce of the flat gradient buffer over
+    the ranks (RCCL; accelerate's DDP in the reference), the global gradient norm, and ONE fused clip + Adam + EMA kernel
+    (dpc_adam_ema_step).  The inference scripts only use the checkpoint reader (`load`), which needs no GPU state.
+
+    Differences a maintainer should know: the data loader is not wrapped by accelerate -- each rank draws its own
+    `train_batch_size / world` samples (split_batches = True semantics, :881); noise and t come from torch's device RNG
+    seeded per rank; the EMA is kept on every rank (identical bits) instead of the main process only."""
+
+    def __init__(self, diffusion_model, dataset=None, dataset_path=None, *, train_batch_size=16, gradient_accumulate_every=1,
+                 train_lr=1e-4, train_num_steps=100000, ema_update_every=10, ema_decay=0.995, adam_betas=(0.9, 0.99),
+                 save_and_sample_every=1000, num_samples=25, results_path="./results", amp=False, fp16=False, split_batches=True,
+                 is_schedule=True, resume=False, resume_step=0, is_w_model=True, bwd_mode="x6", loss_scale=1.0, data=None,
+                 max_grad_norm=1.0, **unused):
         from pathlib import Path
         self.model = diffusion_model
         self.channels = diffusion_model.channels
         self.results_path = Path(results_path)
         self.step = 0
+        self.dataset, self.dataset_path = dataset, dataset_path
+        self.batch_size = train_batch_size
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.train_lr, self.adam_betas = train_lr, tuple(adam_betas)
+        self.train_num_steps = train_num_steps
+        self.save_and_sample_every = save_and_sample_every
+        self.is_schedule, self.is_w_model = is_schedule, is_w_model
+        self.max_grad_norm = max_grad_norm
+        self.bwd_mode, self.loss_scale = bwd_mode, loss_scale
+        self.ema_sched = _EmaSchedule(beta=ema_decay, update_every=ema_update_every)
+        self._data = data
+        self._t = None                  # TrainableUnet3D, built on first use (the checkpoint reader needs none of this)
+        self.losses = []
 
     @property
     def device(self):
         return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
+    # ------------------------------------------------------------------ checkpoints (:942-985)
     def load(self, milestone):
         path = str(self.results_path / f"model-{milestone}.pt")
         data = torch.load(path, map_location="cpu")
         sd = {k: v for k, v in data["model"].items() if not k.endswith("rotary_emb.freqs")}
         self.model.load_state_dict(sd)
         self.step = data.get("step", 0)
+        opt = data.get("opt")
+        if self._t is not None:
+            self._after_weight_change(reload=True)
+            if isinstance(opt, dict) and "exp_avg" in opt:
+                self.m.copy_(opt["exp_avg"].to(self.m.device))
+                self.v.copy_(opt["exp_avg_sq"].to(self.v.device))
+                self.opt_step = int(opt["step"])
+        self._loaded_opt = opt
 
     def save(self, milestone):
         self.results_path.mkdir(exist_ok=True, parents=True)
-        data = {"step": self.step, "model": self.model.state_dict(), "opt": None, "ema": None, "scaler": None}
+        opt = ema = None
+        if self._t is not None:
+            opt = {"step": self.opt_step, "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu(), "lr": self._lr(), "betas": self.adam_betas,
+                   "layout": dict(self._t.offsets)}
+            ema = {"ema_model.model." + k: self.ema[o:o + self._t.ctx.W[k].numel()].view(self._t.ctx.W[k].shape).cpu()
+                   for k, o in self._t.offsets.items()}
+            ema["initted"], ema["step"] = torch.tensor(self.ema_sched.initted), torch.tensor(self.ema_sched.step)
+        data = {"step": self.step, "model": self.model.state_dict(), "opt": opt, "ema": ema, "scaler": None}
         torch.save(data, str(self.results_path / f"model-{milestone}.pt"))
+
+    # ------------------------------------------------------------------ training state
+    def _ensure(self):
+        if self._t is not None:
+            return self._t
+        gd = self.model
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("Trainer.train needs a GPU: libdpc has no CPU path")
+        gd.to(dev)
+        self._t = T = gd.trainable(bwd_mode=self.bwd_mode, loss_scale=self.loss_scale)
+        self.m = torch.zeros_like(T.w)
+        self.v = torch.zeros_like(T.w)
+        self.ema = T.w.clone()                                   # EMA(model): deep copy of the online weights (:920)
+        self.norm = torch.zeros(1, device=dev)
+        self.opt_step = 0
+        self._acc = torch.zeros_like(T.g) if self.gradient_accumulate_every > 1 else None
+        return T
+
+    def _after_weight_change(self, reload=False):
+        T = self._t
+        if reload:                                               # load_state_dict re-bound nothing: parameters are views of T.w
+            pass
+        T.version += 1
+        T.module._dirty = True
+
+    def _lr(self):
+        """MultiStepLR(milestones [50000, 150000, 300000], gamma 0.1) (:914), stepped once per optimizer step (:1037)."""
+        if not self.is_schedule:
+            return self.train_lr
+        return self.train_lr * 0.1 ** sum(1 for m in (50000, 150000, 300000) if self.opt_step >= m)
+
+    def loss_and_gradients(self, state, t=None, noise=None):
+        """One p_losses forward + backward on this rank's samples (state [b, F, 6, H, W] on the device): returns the loss
+        (device tensor); the flat gradient is in self._t.g (times loss_scale)."""
+        T, gd = self._ensure(), self.model
+        state = state.to(device=T.device, dtype=torch.float32).contiguous()
+        coff = 3 if (self.is_w_model and state.shape[2] != self.channels) else 0           # Trainer.train :1018-1019
+        b = state.shape[0]
+        if t is None:
+            t = torch.randint(0, gd.num_timesteps, (b,), device=T.device).long()           # GaussianDiffusion.forward :837
+        if noise is None:
+            noise = torch.randn(b, state.shape[1], self.channels, *state.shape[3:], device=T.device)
+        return T.p_losses(state, t.to(T.device), noise.to(T.device).contiguous(), gd.sqrt_alphas_cumprod,
+                          gd.sqrt_one_minus_alphas_cumprod, channel_offset=coff)
+
+    def optimizer_step(self):
+        """clip_grad_norm_(1.0) -> Adam -> scheduler -> EMA (:1027-1043) on the flat buffers; gradients are first summed over
+        the ranks (one all-reduce) and divided by the world size, as DDP's gradient averaging does."""
+        from ..parallel import allreduce_sum_
+        T, L = self._t, _lib.lib()
+        g = T.g if self._acc is None else self._acc
+        world = allreduce_sum_(g)
+        ginv = 1.0 / (T.loss_scale * world * (self.gradient_accumulate_every if self._acc is not None else 1))
+        p, n = T.ctx.ws(L.dpc_reduce_workspace_bytes())
+        _lib.check(L.dpc_l2_norm(_lib.ptr(g), g.numel(), ginv, _lib.ptr(self.norm), p, n, _lib.stream()))
+        mode, wgt = self.ema_sched.next()
+        lr = self._lr()
+        self.opt_step += 1
+        _lib.check(L.dpc_adam_ema_step(_lib.ptr(T.w), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v), _lib.ptr(self.ema), g.numel(),
+                                       _lib.ptr(self.norm), float(self.max_grad_norm or 0.0), ginv, lr, self.adam_betas[0],
+                                       self.adam_betas[1], 1e-8, self.opt_step, mode, wgt, _lib.stream()))
+        self._after_weight_change()
+
+    def train_step(self, batches):
+        """One iteration of Trainer.train's while loop (:1011-1051) given `gradient_accumulate_every` batches."""
+        T = self._ensure()
+        total = None
+        for i, state in enumerate(batches):
+            loss = self.loss_and_gradients(state)
+            if self._acc is not None:
+                if i == 0:
+                    self._acc.copy_(T.g)
+                else:
+                    T.ctx.add_(self._acc, T.g)
+            total = loss if total is None else total + loss
+        self.optimizer_step()
+        self.step += 1
+        return total / len(batches)
+
+    def _loader(self):
+        if self._data is not None:
+            return self._data
+        from torch.utils.data import DataLoader
+        from ..dataset.data_2d import Smoke
+        from .. import parallel
+        assert self.dataset == "Smoke", "the smoke trainer reads the Smoke dataset (:876-881)"
+        ds = Smoke(self.dataset_path, is_train=True)
+        world = parallel.world_size()
+        dl = DataLoader(ds, batch_size=max(1, self.batch_size // world), shuffle=True, pin_memory=True, num_workers=8)
+
+        def cycle():
+            while True:
+                for d in dl:
+                    yield d
+        return cycle()
+
+    def train(self, log_every=10):
+        """Trainer.train (:998-1054): loop to train_num_steps, checkpoint every save_and_sample_every steps."""
+        from .. import parallel
+        self._ensure()
+        it = iter(self._loader())
+        while self.step < self.train_num_steps:
+            batches = []
+            for _ in range(self.gradient_accumulate_every):
+                item = next(it)
+                batches.append(item[0] if isinstance(item, (tuple, list)) else item)
+            loss = self.train_step(batches)
+            if self.step % log_every == 0:
+                self.losses.append((self.step, float(loss.item())))
+                if parallel.rank() == 0:
+                    print(f"step: {self.step}, loss: {self.losses[-1][1]:.4f}, LR: {self._lr()}", flush=True)
+            if self.step % self.save_and_sample_every == 0 and parallel.rank() == 0:
+                self.save(self.step // self.save_and_sample_every)
+        if parallel.rank() == 0:
+            print("training complete")

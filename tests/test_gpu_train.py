@@ -58,3 +58,100 @@ def test_loss_and_every_gradient_match_the_reference(tag, bwd_mode, dev):
     loss = T.p_losses(x0, torch.from_numpy(g["s0:t"]).to(dev), torch.from_numpy(g["s0:noise"]).to(dev), a, b, channel_offset=coff)
     assert abs(loss.item() - float(g["s0:loss"])) < 1e-5 * float(g["s0:loss"])
     _check_grads(T, g, 0, 1e-4)
+
+
+def _trainer(g, dev, bwd_mode="x6", **kw):
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, Trainer
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    ch = int(g["channels"])
+    m = Unet3D_with_Conv3D(dim=int(g["dim"]), dim_mults=tuple(int(v) for v in g["dim_mults"]), channels=ch)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w0:")})
+    gd = GaussianDiffusion(m, image_size=int(g["hw"]), frames=int(g["frames"]), timesteps=1000, sampling_timesteps=250, loss_type="l2",
+                           objective="pred_noise", device=dev)
+    return Trainer(gd, "Smoke", None, train_batch_size=2, train_lr=float(g["lr"]), is_w_model=(ch == 2), bwd_mode=bwd_mode, **kw)
+
+
+@pytest.mark.parametrize("tag", ["joint", "w", "wide"])
+def test_optimizer_steps_match_the_reference(tag, dev):
+    """Trainer.train's step (:1011-1043): backward, clip_grad_norm_(1.0), Adam(lr 1e-3, betas (0.9, 0.99)), on the reference's
+    recorded batches; the gradient norm and the post-Adam weights of step 1 and step 2 against the reference's."""
+    g = load_golden(f"train_{tag}")
+    tr = _trainer(g, dev)
+    lr = float(g["lr"])
+    for step in range(1 if tag == "wide" else 2):
+        loss = tr.loss_and_gradients(torch.from_numpy(g[f"s{step}:state"]).to(dev), torch.from_numpy(g[f"s{step}:t"]).to(dev),
+                                     torch.from_numpy(g[f"s{step}:noise"]).to(dev))
+        assert abs(loss.item() - float(g[f"s{step}:loss"])) < 2e-5 * float(g[f"s{step}:loss"]), (step, loss.item())
+        _check_grads(tr._t, g, step, 2e-4 if step else 1e-4)
+        tr.optimizer_step()
+        assert abs(tr.norm.item() - float(g[f"s{step}:grad_norm"])) < 1e-4 * float(g[f"s{step}:grad_norm"])
+        G = max(float(np.abs(g[f"s0:g:{k}"]).max()) for k in tr._t.names)
+        sd = tr.model.model.state_dict()
+        for k in tr._t.names:
+            ref = torch.from_numpy(g[f"s{step}:w:{k}"])
+            d = (sd[k].cpu() - ref).abs()
+            # Adam's first steps move a weight by ~lr sign(g): elements whose recorded gradient is rounding noise take an
+            # arbitrary +-lr step on either side; everything else must agree to a fraction of lr
+            live = torch.from_numpy(np.abs(g[f"s0:g:{k}"]) > 1e-4 * G)
+            assert d[live].numel() == 0 or d[live].max().item() < 3e-2 * lr, (step, k, d[live].max().item())
+            assert d.max().item() < 2.1 * lr * (step + 1), (step, k)
+
+
+def test_training_step_is_bit_reproducible_and_inference_sees_the_trained_weights(dev):
+    g = load_golden("train_joint")
+    outs = []
+    for _ in range(2):
+        tr = _trainer(g, dev)
+        for step in range(2):
+            tr.loss_and_gradients(torch.from_numpy(g[f"s{step}:state"]).to(dev), torch.from_numpy(g[f"s{step}:t"]).to(dev),
+                                  torch.from_numpy(g[f"s{step}:noise"]).to(dev))
+            tr.optimizer_step()
+        outs.append((tr._t.w.clone(), tr._t.g.clone(), tr.ema.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))         # fixed-order reductions everywhere: bit-identical
+    # the denoiser's inference path (dpc_unet3d_forward) runs on the updated weights: compare with the oracle on them
+    from oracle import unet3d as O
+    cfg = O.Unet3DConfig(dim=int(g["dim"]), dim_mults=tuple(int(v) for v in g["dim_mults"]), channels=int(g["channels"]))
+    sd = {k: v.detach().cpu().clone() for k, v in tr.model.model.state_dict().items()}
+    x = torch.from_numpy(g["s0:state"])
+    t = torch.from_numpy(g["s0:t"])
+    with torch.no_grad():
+        ref = O.unet3d_forward(sd, cfg, x, t)
+    y = tr.model.model(x.to(dev), t.to(dev)).cpu()
+    assert ((y - ref).abs().max() / ref.abs().max()).item() < 1e-4
+    assert (sd["init_conv.weight"] - torch.from_numpy(g["w0:init_conv.weight"])).abs().max() > 1e-4      # they did move
+
+
+@pytest.mark.parametrize("bwd_mode,loss_scale", [("x6", 1.0), ("f16x3", 2.0 ** 20)])
+def test_full_width_gradients_vs_autograd_on_the_oracle(bwd_mode, loss_scale, dev):
+    """dim 64, mults (1, 2, 4) -- the widths train_2d_smoke.py:43-47 builds -- at 8 frames x 16 x 16, B = 2: every parameter
+    gradient against torch autograd through the CPU oracle.  'f16x3' runs the backward-data convolutions on 22-bit split operands
+    with a power-of-two loss scale (undone by the optimizer kernel)."""
+    from oracle import train_smoke as TS
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from diffphycon_amd.model.video_diffusion_pytorch.unet3d_train import TrainableUnet3D
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=61)
+    gen = torch.Generator().manual_seed(62)
+    x0 = torch.randn(2, 8, 6, 16, 16, generator=gen) * 0.5
+    noise = torch.randn(2, 8, 6, 16, 16, generator=gen)
+    t = torch.tensor([700, 40])
+    sched = TS.schedule(1000)
+    loss_ref, grads_ref = TS.loss_and_grads(sd, cfg, sched, x0, t, noise)
+    m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6)
+    m.load_state_dict(sd)
+    T = TrainableUnet3D(m, dev, bwd_mode=bwd_mode, loss_scale=loss_scale)
+    a, b = _sched(dev)
+    loss = T.p_losses(x0.to(dev), t.to(dev), noise.to(dev), a, b)
+    assert abs(loss.item() - loss_ref.item()) < 2e-5 * loss_ref.item()
+    G = max(v.abs().max().item() for v in grads_ref.values())
+    worst, bad = 0.0, []
+    for k, ref in grads_ref.items():
+        got = T.ctx.G[k].cpu().reshape(ref.shape) / loss_scale
+        err = (got - ref).abs().max().item()
+        rel = err / (ref.abs().max().item() + 1e-5 * G)
+        worst = max(worst, rel)
+        if rel > 5e-4:
+            bad.append((k, rel))
+    print(f"full-width gradients ({bwd_mode}): worst relative deviation {worst:.2e} over {len(grads_ref)} tensors")
+    assert not bad, bad[:8]
