@@ -150,7 +150,7 @@ _SIGNATURES = {
     "dpc_stem_free": (None, [_P]),
     "dpc_stem_run": (C.c_int, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "dpc_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _L]),
-    "dpc_conv_wgrad_cl": (C.c_int, [_P, _P, _P] + [_I] * 19 + [C.c_float, _I, _P, _Z, _P]),
+    "dpc_conv_wgrad_cl": (C.c_int, [_P, _P, _P] + [_I] * 19 + [C.c_float, C.c_float, _I, _P, _Z, _P]),
     "dpc_colsum_workspace_bytes": (_Z, [_I]),
     "dpc_colsum": (C.c_int, [_P, _P, _P, _P, _L, _I, C.c_float, _I, _P, _Z, _P]),
     "dpc_gn_silu_bwd_params": (C.c_int, [_P] * 10 + [_I, _L, _I, _I, _P, _Z, _P]),

@@ -91,7 +91,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 enum ProfClass {
     PROF_IGEMM64 = 0, PROF_IGEMM128, PROF_STEM, PROF_GN, PROF_LN, PROF_ATTN, PROF_LINATTN, PROF_UPDATE, PROF_SMALL,
     PROF_BURGERS, PROF_PHILOX, PROF_SMOKE_EVAL, PROF_CONV3H64, PROF_CONV3H128, PROF_TATTN_FUSED, PROF_LATTN_FUSED, PROF_CONV3X6_64,
-    PROF_CONV3X6_128, PROF_WGRAD, PROF_ATTN_BWD, PROF_TRAIN_MISC, PROF_NCLASS
+    PROF_CONV3X6_128, PROF_WGRAD, PROF_ATTN_BWD, PROF_TRAIN_MISC, PROF_WGRAD3, PROF_NCLASS
 };
 struct ProfScope {
     ProfScope(int cls, double flops, double bytes, hipStream_t s);
@@ -299,6 +299,11 @@ int launch_gn_silu_bwd(const float* x, const float* dy, const float* stats, cons
                        hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr);
 // d gamma / d beta [C] of the same GroupNorm from the partial sums launch_gn_silu_bwd's first pass leaves in ws (train.hip)
 int launch_gn_param_grad(const void* ws, const float* scale_shift, float* dgamma, float* dbeta, int B, int C, int nchunk, hipStream_t s);
+// 3x3x3 weight gradient on the fp16 matrix cores (wgrad3.hip): f16x3 operands, x pre-scaled by x_scale, dy by dy_scale (powers of two)
+bool wgrad3_supported(int W, int H, int C, int N);
+size_t wgrad3_workspace_bytes(int C, int N, long long planes);
+int launch_wgrad3(const float* x, const float* dy, float* dw, int B, int F, int H, int W, int C, int N, int ctot, int coff, float x_scale,
+                  float dy_scale, float out_scale, int accumulate, void* ws, hipStream_t s);
 // backward of the channel LayerNorm y = (x - mean) * rstd * g: dx (= or +=) per row
 int launch_ln_bwd(const float* x, const float* stats, const float* g, const float* dy, float* dx, long long rows, int C, int accum,
                   hipStream_t s);

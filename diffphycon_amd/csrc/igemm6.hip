@@ -14,6 +14,8 @@
 // igemm3_kernel (default, DPC_IGEMM_MODE=f16x3) is the same kernel with the 2-way fp16 operand split of conv3f3.hip:
 // 22-bit operands pre-scaled by 2^4 / 2^12, three partial products per product, A rows of 2 planes x 32 k fp16 = 128 B
 // + 16 B pad (144 B = 9 x 16 B), weights [iteration][n][2 planes][32 k] fp16, epilogue rescale by 2^-16.
+#include <algorithm>
+
 #include "common.h"
 
 namespace dpc {
@@ -598,9 +600,10 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
             static size_t cap = 0;
             const size_t need = (size_t)nsl * p.M * p.N * sizeof(float);
             if (need > cap) {
-                if (scratch) (void)hipFree(scratch);
-                DPC_HIP(hipMalloc(&scratch, need));
-                cap = need;
+                // grown geometrically and NEVER freed: a captured HIP graph (Burgers sampler) may still hold the old pointer
+                const size_t want = std::max(need, 2 * cap);
+                DPC_HIP(hipMalloc(&scratch, want));
+                cap = want;
             }
             IgemmParams q = p;
             q.ksplit = nsl;

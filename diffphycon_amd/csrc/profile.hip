@@ -12,7 +12,7 @@ static const char* kClassNames[PROF_NCLASS] = {
     "igemm_bn64", "igemm_bn128", "stem_gather", "groupnorm_silu", "ln_stats", "attention_core",
     "linear_attention", "ddpm_update", "small_ops", "burgers_fd", "philox_normal", "smoke_eval", "conv3h_bn64",
     "conv3h_bn128", "temporal_attention_fused",
-    "linear_attention_fused", "conv3x6_bn64", "conv3x6_bn128", "conv_wgrad", "attention_bwd", "train_misc"};
+    "linear_attention_fused", "conv3x6_bn64", "conv3x6_bn128", "conv_wgrad", "attention_bwd", "train_misc", "conv3_wgrad_f16x3"};
 
 struct ProfState {
     bool on = false;

@@ -9,6 +9,7 @@
 // All reductions run in a fixed order (two-stage, no float atomics): a training step is bit-reproducible run to run.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -221,40 +222,55 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
+// 16 channels x 16 partial lanes per block: lane j adds partials j, j + 16, ... in order, then the 16 lane sums are added in order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out, int C, int nblk,
                                                           float scale, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0;
-    for (int k = 0; k < nblk; ++k) s += part[(long long)k * C + c];
-    const float v = (float)(s * (double)scale);
-    out[c] = accumulate ? out[c] + v : v;
+    if (c < C)
+        for (int k = j; k < nblk; k += 16) s += part[(long long)k * C + c];
+    red[j][cl] = s;
+    __syncthreads();
+    if (j == 0 && c < C) {
+        double t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        const float v = (float)(t * (double)scale);
+        out[c] = accumulate ? out[c] + v : v;
+    }
 }
 
 // GroupNorm affine gradients from the per-(sample, chunk, channel) partial sums (A = sum dz, Bs = sum dz xhat) that
 // gn_bwd_partial_kernel (norm.hip) leaves in the workspace: dgamma[c] = sum_b (scale_b,c + 1) Bs, dbeta[c] = sum_b (scale_b,c + 1) A
 __global__ __launch_bounds__(256) void gn_param_grad_kernel(const double* __restrict__ part, const float* __restrict__ scale_shift,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int nchunk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // 16 channels x 16 lanes per block; lane j takes the (sample, chunk) pairs j, j + 16, ... in order; fixed-order finish
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double dg = 0, db = 0;
-    for (int b = 0; b < B; ++b) {
-        double A = 0, Bs = 0;
-        for (int k = 0; k < nchunk; ++k) {
-            const double* src = part + (((long long)b * nchunk + k) * C + c) * 2;
-            A += src[0];
-            Bs += src[1];
+    if (c < C)
+        for (int idx = j; idx < B * nchunk; idx += 16) {
+            const int b = idx / nchunk;
+            const double* src = part + ((long long)idx * C + c) * 2;
+            const double sc = scale_shift ? (double)scale_shift[(long long)b * 2 * C + c] + 1.0 : 1.0;
+            db += sc * src[0];
+            dg += sc * src[1];
         }
-        const double sc = scale_shift ? (double)scale_shift[(long long)b * 2 * C + c] + 1.0 : 1.0;
-        dg += sc * Bs;
-        db += sc * A;
+    red[0][j][cl] = dg;
+    red[1][j][cl] = db;
+    __syncthreads();
+    if (j == 0 && c < C) {
+        double tg = 0, tb = 0;
+        for (int k = 0; k < 16; ++k) { tg += red[0][k][cl]; tb += red[1][k][cl]; }
+        dgamma[c] = (float)tg;
+        dbeta[c] = (float)tb;
     }
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
 }
 
 int launch_gn_param_grad(const void* ws, const float* scale_shift, float* dgamma, float* dbeta, int B, int C, int nchunk, hipStream_t s) {
-    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double*>(ws), scale_shift,
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((C + 15) / 16), dim3(256), 0, s, reinterpret_cast<const double*>(ws), scale_shift,
                        dgamma, dbeta, B, C, nchunk);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
@@ -440,6 +456,140 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const TattnBwdParams p) 
     }
 }
 
+// The same backward for L <= 32 tokens on the fp32 matrix cores: one WAVE per (sequence, head), persistent, wave-private LDS
+// (q', k', v | P^T, dO, dS^T as [32][33] fp32); every product is a 32 x 32 x 32 fp32 GEMM = 16 v_mfma_f32_32x32x2_f32:
+//   S^T = K' Q'^T (+ bias^T)  -> softmax over the key axis = over a lane's 16 registers + its partner lane (l ^ 32)
+//   dP^T = V dO^T;  dS^T = P^T (dP^T - t_i);  dV = P^T dO;  dK' = dS^T Q';  dQ' = dS K'
+// Scores are kept TRANSPOSED (lane = query) so that the softmax statistics are lane-local; P^T / dS^T pass through LDS once to
+// become A operands.  A wave keeps ONE head (bias and rotary rows in registers) and accumulates that head's bias gradient in the
+// accumulator layout across its sequences; partials [wave][L][L] are reduced in fixed order by tattn_dbias_final_kernel.
+struct TattnBwdMParams {
+    TattnBwdParams b;
+    int waves_per_head;    // total waves / heads
+};
+
+__global__ __launch_bounds__(256) void tattn_bwd_mfma_kernel(const TattnBwdMParams pp) {
+    const TattnBwdParams& p = pp.b;
+    extern __shared__ float s_tm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave;
+    const int head = gw % p.heads, wslot = gw / p.heads;
+    const int L = p.L, ld = 3 * p.heads * 32, HD = p.heads * 32;
+    const float scale = 0.17677669529663687f;
+    float* sq = s_tm + wave * (5 * 32 * 33);
+    float* sk = sq + 32 * 33;
+    float* sv = sk + 32 * 33;          // v, later P^T
+    float* sd = sv + 32 * 33;          // dO
+    float* st = sd + 32 * 33;          // dS^T
+    auto rowof = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * hh; };
+    // per-lane constants: bias^T column (query i = l31, keys = this lane's rows), rotary rows for the output tokens
+    float bias_r[16], dbias_r[16], crow[16], srow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = rowof(r);
+        bias_r[r] = (j < L && l31 < L) ? (p.bias ? p.bias[((long long)head * L + l31) * L + j] : 0.f) : -INFINITY;
+        if (j < L && l31 >= L) bias_r[r] = 0.f;                    // inactive query columns: finite scores, zero gradients
+        dbias_r[r] = 0.f;
+        const int tok = j;                                         // output tiles: rows = tokens, lane = head dim d = l31
+        const bool in = p.rot_cos && tok < L;
+        crow[r] = in ? p.rot_cos[tok * 32 + l31] : 1.f;
+        // rot^T: out[d] = c[d] g[d] + s[d ^ 1] g[d ^ 1] (d even) | c[d] g[d] - s[d ^ 1] g[d ^ 1] (d odd)
+        srow[r] = in ? ((l31 & 1) ? -p.rot_sin[tok * 32 + (l31 ^ 1)] : p.rot_sin[tok * 32 + (l31 ^ 1)]) : 0.f;
+    }
+    for (long long seq = wslot; seq < p.n_seq; seq += pp.waves_per_head) {
+        const long long base_row = (seq / p.seq_inner) * p.seq_outer_stride + (seq % p.seq_inner) * p.seq_inner_stride;
+        // ---- stage q' (scaled, rotated), k' (rotated), v, dO: lane -> (token = idx / 8, 4 dims)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = lane + 64 * u, tok = idx >> 3, c4 = (idx & 7) * 4;
+            const bool in = tok < L;
+            const long long row = base_row + (long long)tok * p.token_stride;
+            const float* src = p.qkv + row * ld + head * 32 + c4;
+            f32x4 q = in ? *reinterpret_cast<const f32x4*>(src) : f32x4{0, 0, 0, 0};
+            f32x4 k = in ? *reinterpret_cast<const f32x4*>(src + HD) : f32x4{0, 0, 0, 0};
+            const f32x4 v = in ? *reinterpret_cast<const f32x4*>(src + 2 * HD) : f32x4{0, 0, 0, 0};
+            const f32x4 d = in ? *reinterpret_cast<const f32x4*>(p.dout + row * HD + head * 32 + c4) : f32x4{0, 0, 0, 0};
+            q = q * scale;
+            if (p.rot_cos && in) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rot_cos + tok * 32 + c4);
+                const f32x4 s = *reinterpret_cast<const f32x4*>(p.rot_sin + tok * 32 + c4);
+                q = f32x4{q[0] * c[0] - q[1] * s[0], q[1] * c[1] + q[0] * s[1], q[2] * c[2] - q[3] * s[2], q[3] * c[3] + q[2] * s[3]};
+                k = f32x4{k[0] * c[0] - k[1] * s[0], k[1] * c[1] + k[0] * s[1], k[2] * c[2] - k[3] * s[2], k[3] * c[3] + k[2] * s[3]};
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sq[tok * 33 + c4 + e] = q[e];
+                sk[tok * 33 + c4 + e] = k[e];
+                sv[tok * 33 + c4 + e] = v[e];
+                sd[tok * 33 + c4 + e] = d[e];
+            }
+        }
+        // (wave-private LDS: DS operations of a wave complete in order, no barrier needed)
+        f32x16 sT, dpT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sT[r] = bias_r[r]; dpT[r] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int kk = 2 * s2 + hh;
+            sT = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[l31 * 33 + kk], sq[l31 * 33 + kk], sT, 0, 0, 0);
+            dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l31 * 33 + kk], sd[l31 * 33 + kk], dpT, 0, 0, 0);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sT[r]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sT[r] = expf(sT[r] - m); l += sT[r]; }
+        l += __shfl_xor(l, 32, 64);
+        const float il = 1.0f / l;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sT[r] *= il; t += sT[r] * dpT[r]; }
+        t += __shfl_xor(t, 32, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dpT[r] = sT[r] * (dpT[r] - t);                       // dS^T
+            dbias_r[r] += dpT[r];
+            sv[rowof(r) * 33 + l31] = sT[r];                      // P^T [j][i] over v (its last MFMA read is issued above)
+            st[rowof(r) * 33 + l31] = dpT[r];
+        }
+        f32x16 dv, dk, dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; dq[r] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int kk = 2 * s2 + hh;
+            const float bd = sd[kk * 33 + l31], bq = sq[kk * 33 + l31], bk = sk[kk * 33 + l31];
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l31 * 33 + kk], bd, dv, 0, 0, 0);       // P^T[j][i] dO[i][d]
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(st[l31 * 33 + kk], bq, dk, 0, 0, 0);       // dS^T[j][i] q'[i][d]
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(st[kk * 33 + l31], bk, dq, 0, 0, 0);       // dS[i][j] k'[j][d]
+        }
+        // ---- rot^T (pairs are neighbouring lanes), q scale, stores: rows = tokens, 32 lanes = one 128-byte row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tok = rowof(r);
+            const float gq = dq[r], gk = dk[r];
+            const float pq = __shfl_xor(gq, 1, 64), pk = __shfl_xor(gk, 1, 64);
+            if (tok < L) {
+                float* o = p.dqkv + (base_row + (long long)tok * p.token_stride) * ld + head * 32 + l31;
+                o[0] = (crow[r] * gq + srow[r] * pq) * scale;
+                o[HD] = crow[r] * gk + srow[r] * pk;
+                o[2 * HD] = dv[r];
+            }
+        }
+    }
+    if (p.dbias_part) {
+        float* dst = p.dbias_part + ((long long)wslot * p.heads + head) * L * L;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = rowof(r);
+            if (j < L && l31 < L) dst[l31 * L + j] = dbias_r[r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tattn_dbias_final_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nwg, int n,
                                                                int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,12 +750,14 @@ extern "C" {
 size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows) {
     const int fpr = (kw * C + 31) / 32;
     const int nrf = kf * kh * fpr, ncf = (N + 31) / 32;
-    return (size_t)wgrad_slabs(nrf, ncf, rows) * nrf * 32 * ncf * 32 * sizeof(float) + 512;
+    size_t need = (size_t)wgrad_slabs(nrf, ncf, rows) * nrf * 32 * ncf * 32 * sizeof(float) + 512;
+    if (kf == 3 && kh == 3 && kw == 3 && C % 32 == 0 && N % 64 == 0) need = std::max(need, wgrad3_workspace_bytes(C, N, rows));
+    return need;
 }
 
 int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, int Hi, int Wi, int C, int Ho, int Wo, int N, int kf,
                       int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
-                      int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream) {
+                      float f16_dy_scale, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream) {
     DPC_REQUIRE(x && dy && dw && ws, "conv_wgrad: null argument");
     DPC_REQUIRE(B >= 1 && F >= 1 && C >= 1 && N >= 1 && kf >= 1 && kh >= 1 && kw >= 1 && sh >= 1 && sw >= 1, "conv_wgrad: bad shape");
     DPC_REQUIRE(C % 32 == 0 || 32 % C == 0, "conv_wgrad: input channels must divide or be a multiple of 32 (pad on the host)");
@@ -613,6 +765,15 @@ int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, 
     if (c_valid <= 0) c_valid = C;
     DPC_REQUIRE(c_valid <= C && dw_coff >= 0 && dw_coff + c_valid <= dw_ctot, "conv_wgrad: bad weight channel slice");
     hipStream_t s = (hipStream_t)stream;
+    if (f16_dy_scale != 0.f) {
+        int e = 0;
+        DPC_REQUIRE(f16_dy_scale > 0.f && std::frexp(f16_dy_scale, &e) == 0.5f, "conv_wgrad: f16_dy_scale must be a power of two (or 0)");
+        if (kf == 3 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && pf == 1 && ph == 1 && pw == 1 && Hi == Ho && Wi == Wo && c_valid == C &&
+            wgrad3_supported(Wi, Hi, C, N)) {
+            DPC_REQUIRE(ws_bytes >= wgrad3_workspace_bytes(C, N, (long long)B * F), "conv_wgrad: workspace too small");
+            return launch_wgrad3(x, dy, dw, B, F, Hi, Wi, C, N, dw_ctot, dw_coff, 16.0f, f16_dy_scale, scale, accumulate, ws, s);
+        }
+    }
     WgradParams p{};
     p.x = x; p.dy = dy;
     p.B = B; p.F = F; p.Hi = Hi; p.Wi = Wi; p.C = C; p.Ho = Ho; p.Wo = Wo; p.N = N;
@@ -654,7 +815,7 @@ int dpc_colsum(const float* dy, const float* x, const float* ln_stats, float* ou
     ProfScope prof(PROF_TRAIN_MISC, 0, 4.0 * (double)rows * C * (x ? 2 : 1), s);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, s, dy, x, ln_stats, part, (long long)rows, C, nblk);
     DPC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, out, C, nblk, scale, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, out, C, nblk, scale, accumulate);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
@@ -670,6 +831,38 @@ int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, floa
     DPC_REQUIRE(!dbias || (ws && ws_bytes >= dpc_attention_bwd_seq_workspace_bytes(heads, L)), "attention_bwd_seq: workspace too small");
     if (n_seq == 0) return DPC_OK;
     hipStream_t s = (hipStream_t)stream;
+    static const int use_mfma = [] { const char* e = getenv("DPC_TATTN_BWD_MFMA"); return e ? atoi(e) : 1; }();
+    if (L <= 32 && use_mfma) {
+        // one wave per (sequence, head); waves-per-head partial slots for the bias gradient (<= 512 as the workspace is sized)
+        long long waves = std::min<long long>((n_seq * heads + 3) / 4 * 4, 256 * 4);
+        waves = std::max<long long>(heads * 4, waves / (heads * 4) * (heads * 4));       // multiple of 4 (workgroup) and of heads
+        TattnBwdMParams q{};
+        q.b.qkv = qkv; q.b.dout = dout; q.b.dqkv = dqkv; q.b.heads = heads; q.b.L = L;
+        q.b.n_seq = n_seq; q.b.seq_inner = seq_inner; q.b.seq_outer_stride = seq_outer_stride_rows;
+        q.b.seq_inner_stride = seq_inner_stride_rows; q.b.token_stride = token_stride_rows;
+        q.b.rot_cos = rot_cos; q.b.rot_sin = rot_sin; q.b.bias = bias;
+        q.b.dbias_part = dbias ? reinterpret_cast<float*>(align_up((size_t)ws, 256)) : nullptr;
+        q.waves_per_head = (int)(waves / heads);
+        DPC_REQUIRE(q.waves_per_head <= 512, "attention_bwd_seq: too many heads for the bias-gradient workspace");
+        const size_t lds = (size_t)4 * 5 * 32 * 33 * sizeof(float);
+        static bool once_m = false;
+        if (!once_m) {
+            DPC_HIP(hipFuncSetAttribute((const void*)tattn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            once_m = true;
+        }
+        {
+            ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)n_seq * heads * L * L * 32, 0, s);
+            hipLaunchKernelGGL(tattn_bwd_mfma_kernel, dim3((unsigned)(waves / 4)), dim3(256), lds, s, q);
+            DPC_LAUNCH_CHECK();
+        }
+        if (dbias) {
+            const int n = heads * L * L;
+            hipLaunchKernelGGL(tattn_dbias_final_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q.b.dbias_part, dbias, q.waves_per_head, n,
+                               accumulate_dbias);
+            DPC_LAUNCH_CHECK();
+        }
+        return DPC_OK;
+    }
     const int LP = L <= 32 ? 32 : 64, G = 256 / LP;
     const long long ngroups = (n_seq + G - 1) / G;
     const int nwg = (int)std::min<long long>(ngroups, 512);

@@ -272,7 +272,18 @@ class GaussianDiffusion(nn.Module):
         B = img.shape[0]
         if not self.use_graph:
             return self._denoise(img, x_w, torch.full((B,), t, device=img.device, dtype=torch.long))
+        models = (self.model_uw, self.model_w) if self.eval_two_models else (self.model,)
+        if any(m._dirty or m._device != img.device for m in models):
+            self._graphs.clear()                    # new weights / device: a replay would run the old ones (it skips _sync)
+
+        def stamp():
+            # everything a captured launch sequence bakes in besides the state buffers: the weights' upload generation, the
+            # activation workspace address, the arithmetic mode and the debug-tap switch of each denoiser
+            return tuple((m._version, 0 if m._ws is None else m._ws.data_ptr(), str(m.arithmetic), bool(getattr(m, "_taps", False)))
+                         for m in models)
         key = (img.data_ptr(), 0 if x_w is None else x_w.data_ptr(), tuple(img.shape))
+        if key in self._graphs and self._graphs[key][2] != stamp():
+            del self._graphs[key]
         if key not in self._graphs:
             if len(self._graphs) >= 2:              # (two state buffers when the sampler ping-pongs; anything else: start over)
                 self._graphs.clear()
@@ -290,9 +301,9 @@ class GaussianDiffusion(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._denoise(img, x_w, self._t_static)
-            self._graphs[key] = (g, out)
+            self._graphs[key] = (g, out, stamp())
         self._t_static.fill_(t)
-        g, out = self._graphs[key]
+        g, out, _ = self._graphs[key]
         g.replay()
         return out
 

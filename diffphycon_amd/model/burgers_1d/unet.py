@@ -117,6 +117,8 @@ class Unet2D(nn.Module):
             self._names.append(name)
         self._handle = None
         self._dirty = True
+        self._version = 0                     # upload generation: bumped whenever _sync re-uploads (graph caches key on it)
+        self._taps = False
         self._ws = None
         self._device = None
         self.register_load_state_dict_post_hook(lambda module, _keys: setattr(module, "_dirty", True))
@@ -183,6 +185,7 @@ class Unet2D(nn.Module):
             _lib.check(L.dpc_unet2d_finalize(self._handle))
             self._dirty = False
             self._device = device
+            self._version += 1
 
     def __del__(self):
         try:
@@ -216,6 +219,7 @@ class Unet2D(nn.Module):
     # test hooks
     def debug_taps(self, enable=True):
         self._ensure_handle()
+        self._taps = bool(enable)
         _lib.check(_lib.lib().dpc_unet2d_debug_taps(self._handle, int(enable)))
 
     def get_tap(self, name, shape, device):

@@ -58,6 +58,7 @@ class _Ctx:
         self.W, self.G = {}, {}
         self._ws = None
         self.act_scale = 0.0           # operand scale of the f16x3 backward-data convolutions (0: the library default 2^4)
+        self.wgrad_dy_scale = 0.0      # != 0: 3x3x3 weight gradients on the fp16 matrix cores, dy pre-scaled by this power of two
 
     def ws(self, nbytes):
         nbytes = int(nbytes) + 512
@@ -140,7 +141,7 @@ class _Ctx:
         L = _lib.lib()
         p, n = self.ws(L.dpc_conv_wgrad_workspace_bytes(Cc, N, kd, kh, kw, B * F * Ho))
         _lib.check(L.dpc_conv_wgrad_cl(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, F, Hi, Wi, Cc, Ho, Wo, N, kd, kh, kw, sh, sw, pd, ph, pw,
-                                       c_valid, ctot, coff, 1.0, 0, p, n, _lib.stream()))
+                                       c_valid, ctot, coff, 1.0, self.wgrad_dy_scale, 0, p, n, _lib.stream()))
 
 
 class _Pack:
@@ -481,7 +482,7 @@ class _Up:
 class TrainableUnet3D:
     """Forward-with-tape and backward of a `Unet3D_with_Conv3D` module (its parameters are re-pointed into a flat buffer)."""
 
-    def __init__(self, module, device=None, bwd_mode="x6", fwd_mode=None, loss_scale=1.0):
+    def __init__(self, module, device=None, bwd_mode="x6", fwd_mode=None, loss_scale=1.0, wgrad_mode="f16x3"):
         device = torch.device(device or "cuda")
         if device.type != "cuda":
             raise RuntimeError("TrainableUnet3D needs a GPU (libdpc has no CPU path)")
@@ -493,6 +494,13 @@ class TrainableUnet3D:
         self.loss_scale = float(loss_scale)
         assert math.frexp(self.loss_scale)[0] == 0.5, "loss_scale must be a power of two"
         self.ctx = ctx = _Ctx(device, m.resnet_groups, m.attn_heads, fwd_mode, bwd_mode)
+        if wgrad_mode not in ("f16x3", "f32"):
+            raise ValueError("wgrad_mode: 'f16x3' (3x3x3 weight gradients on the fp16 matrix cores) | 'f32' (native fp32 MFMA)")
+        # the gradient operand of the f16x3 weight-gradient kernel is scaled so that d loss / d eps * 2^24 is what gets split:
+        # d eps ~ 2 (eps - noise) / numel ~ 1e-7 lands at O(1), as it does for the f16x3 backward-data convolutions (loss scale
+        # 2^20 times the operand pre-scale 2^4)
+        ctx.wgrad_dy_scale = (2.0 ** 24) / self.loss_scale if wgrad_mode == "f16x3" else 0.0
+        self.wgrad_mode = wgrad_mode
         # ---- flat parameter / gradient buffers; module parameters become views
         self.names = list(m._names)
         params = dict(m.named_parameters())

@@ -300,11 +300,15 @@ int dpc_stem_run(dpc_stem_t h, const float* x, int x_channels_total, int x_chann
  * (a concatenated input = one call per source; c_valid < C: zero-padded input channels, 0 = C), dw = (accumulate ? dw : 0) +
  * scale * sum_p dy[p][n] x[p + tap][c].  C must divide or be a multiple of 32.  ConvTranspose3d (1,4,4)/(1,2,2)/(0,1,1)
  * (weight [Cin][Cout][1][4][4]): call with x = the transposed conv's OUTPUT gradient and dy = its input, geometry of the
- * (1,4,4)/(1,2,2)/(0,1,1) convolution.  Exact fp32 products (native fp32 MFMA), fixed summation order. */
+ * (1,4,4)/(1,2,2)/(0,1,1) convolution.  Exact fp32 products (native fp32 MFMA), fixed summation order.
+ * f16_dy_scale != 0 (a power of two): the 3x3x3 stride-1 pad-1 convolutions with W in {16, 32, 64}, C % 32 == 0, N % 64 == 0
+ * run on the fp16 matrix cores instead (csrc/wgrad3.hip: LDS transpose reads, f16x3 = 22-bit split operands, 3 MFMAs per product,
+ * fp32 accumulation): x is pre-scaled by 2^4 like every f16x3 activation operand, dy by f16_dy_scale (saturating at 65504), both
+ * undone in the fixed-order reduction; other shapes ignore the flag.  rows of the workspace query: B * F * Ho. */
 size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows /* B * F * Ho */);
 int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, int Hi, int Wi, int C, int Ho, int Wo, int N, int kf,
                       int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
-                      int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream);
+                      float f16_dy_scale, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream);
 /* out[c] = (accumulate ? out[c] : 0) + scale * sum_r dy[r][c] (x NULL: bias gradients) or
  * scale * sum_r dy[r][c] (x[r][c] - mean_r) rstd_r (channel-LayerNorm gamma gradient :195-204, ln_stats [rows][2]); fp64 partials */
 size_t dpc_colsum_workspace_bytes(int C);

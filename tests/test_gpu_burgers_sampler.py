@@ -184,3 +184,26 @@ def test_fopc_recipe_teacher_forced_vs_reference(dev):
             # on the un-clamped elements of x0 (and through them x_out): that step is held to the free-chain tolerance instead
             tol = 1e-4 if (t < 150 or name == "pred_noise") else 5e-3
             assert err < tol, (t, name, err)
+
+
+def test_graph_replay_follows_weight_reloads(g, dev):
+    """The HIP-graph replay of the two denoiser forwards (default on) must never run stale weights: sample, load other weights,
+    sample again -- each against eager launches (use_graph False) of the same state, bit for bit.  The cache is keyed on the
+    state buffers AND the denoisers' upload generation / workspace / mode."""
+    c = CASES["popc"]
+    outs = {}
+    for use_graph in (True, False):
+        gd, kwargs, _ = build(g, c, dev)
+        gd.use_graph = use_graph
+        gd.noise_seed, gd.guidance_batch, gd.noise_epoch = 11, 3, 0
+        a = gd.sample(batch_size=3, **kwargs)
+        sd = {k: v.clone() for k, v in gd.model_uw.state_dict().items()}
+        for k in sd:
+            if k.endswith("weight") and sd[k].dim() > 1:
+                sd[k] = sd[k] * 0.9
+        gd.model_uw.load_state_dict(sd)
+        b = gd.sample(batch_size=3, **kwargs)
+        outs[use_graph] = (a, b)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1], outs[False][1])
+    assert not torch.equal(outs[True][0], outs[True][1])          # the reload changed the result

@@ -155,3 +155,124 @@ def test_full_width_gradients_vs_autograd_on_the_oracle(bwd_mode, loss_scale, de
             bad.append((k, rel))
     print(f"full-width gradients ({bwd_mode}): worst relative deviation {worst:.2e} over {len(grads_ref)} tensors")
     assert not bad, bad[:8]
+
+
+# ------------------------------------------------------------------------------------------------ operator level
+def _cl(x):            # [B, C, F, H, W] -> channels-last rows [B F H W, C]
+    return x.permute(0, 2, 3, 4, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+WGRAD_CASES = [
+    # B, F, Hi, Wi, C, N, k (kd, kh, kw), stride (h, w), pad (d, h, w), f16x3 path?
+    (2, 5, 16, 64, 64, 64, (3, 3, 3), (1, 1), (1, 1, 1), True),
+    (1, 4, 8, 64, 32, 128, (3, 3, 3), (1, 1), (1, 1, 1), True),
+    (2, 3, 32, 32, 64, 64, (3, 3, 3), (1, 1), (1, 1, 1), True),
+    (3, 2, 16, 16, 128, 128, (3, 3, 3), (1, 1), (1, 1, 1), True),
+    (1, 9, 4, 16, 256, 64, (3, 3, 3), (1, 1), (1, 1, 1), True),
+    (2, 3, 8, 8, 64, 64, (3, 3, 3), (1, 1), (1, 1, 1), True),          # W = 8: exact fp32 kernel (flag ignored)
+    (2, 4, 16, 16, 8, 16, (3, 3, 3), (1, 1), (1, 1, 1), False),
+    (1, 3, 6, 10, 64, 96, (3, 3, 3), (1, 1), (1, 1, 1), False),
+    (2, 2, 8, 8, 128, 384, (1, 1, 1), (1, 1), (0, 0, 0), False),
+    (2, 3, 16, 16, 64, 64, (1, 4, 4), (2, 2), (0, 1, 1), False),
+    (1, 8, 16, 16, 8, 64, (7, 7, 7), (1, 1), (3, 3, 3), False),
+    (2, 4, 12, 12, 4, 16, (7, 7, 7), (1, 1), (3, 3, 3), False),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_weight_gradient(case, dev):
+    """dpc_conv_wgrad_cl against torch autograd in fp64: every conv geometry of the denoiser (3x3x3 on the fp16 matrix cores and
+    on the exact fp32 kernel, 1x1x1, the strided (1,4,4) downsample, the 7x7x7 stem with zero-padded channels), with the gradient
+    operand at the magnitudes a mean-reduced loss produces (1e-6) so that the operand scaling is exercised."""
+    import ctypes as C
+    import torch.nn.functional as F_
+    from diffphycon_amd import _lib as L
+    B, Fr, H, W, Ci, N, k, st, pd, f16 = case
+    g = torch.Generator().manual_seed(hash(case) % 2 ** 31)
+    x = torch.randn(B, Ci, Fr, H, W, generator=g)
+    wref = torch.zeros(N, Ci, *k, dtype=torch.float64, requires_grad=True)
+    y = F_.conv3d(x.double(), wref, None, stride=(1,) + st, padding=pd)
+    dy = torch.randn(y.shape, generator=g) * 1e-6
+    y.backward(dy.double())
+    ref = wref.grad.float()
+    Ho, Wo = y.shape[3], y.shape[4]
+    xd, dyd = _cl(x).to(dev), _cl(dy).to(dev)
+    dw = torch.full((N, Ci + 3, *k), 7.0, device=dev)            # written as a channel slice [2, 2 + Ci) of a wider weight
+    lib = L.lib()
+    nb = lib.dpc_conv_wgrad_workspace_bytes(Ci, N, *k, B * Fr * Ho)
+    ws = L.workspace(nb, dev)
+    L.check(lib.dpc_conv_wgrad_cl(L.ptr(xd), L.ptr(dyd), L.ptr(dw), B, Fr, H, W, Ci, Ho, Wo, N, *k, *st, *pd, 0, Ci + 3, 2, 1.0,
+                                  2.0 ** 20 if f16 else 0.0, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    got = dw.cpu()
+    assert torch.all(got[:, :2] == 7.0) and torch.all(got[:, 2 + Ci:] == 7.0)      # nothing outside the slice is touched
+    err = (got[:, 2:2 + Ci] - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-6, err
+
+
+def test_column_reductions_and_small_linear_backward(dev):
+    import ctypes as C
+    from diffphycon_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(3)
+    for rows, Cc in ((4099, 64), (700, 256), (16, 512), (333, 8)):
+        dy, x = torch.randn(rows, Cc, generator=g), torch.randn(rows, Cc, generator=g) * 2 + 0.5
+        mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+        st = torch.stack((mean, (var + 1e-5).rsqrt()), 1).float()
+        ws = L.workspace(lib.dpc_colsum_workspace_bytes(Cc), dev)
+        dyd, xd, std = dy.to(dev), x.to(dev), st.to(dev)          # (named: a temporary would be freed before the kernel runs)
+        for with_x in (False, True):
+            out = torch.empty(Cc, device=dev)
+            L.check(lib.dpc_colsum(L.ptr(dyd), L.ptr(xd) if with_x else None, L.ptr(std) if with_x else None,
+                                   L.ptr(out), rows, Cc, 1.0, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+            ref = (dy.double() * ((x.double() - mean[:, None]) * st[:, 1:].double()) if with_x else dy.double()).sum(0)
+            assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    for B, K, N, act in ((16, 64, 256, 0), (16, 256, 256, 2), (5, 256, 128, 1)):
+        dy, x, Wt = torch.randn(B, N, generator=g), torch.randn(B, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+        xr = x.double().requires_grad_(True)
+        Wr = Wt.double().requires_grad_(True)
+        a = {0: lambda v: v, 1: torch.nn.functional.silu, 2: torch.nn.functional.gelu}[act](xr)
+        (a @ Wr.t()).backward(dy.double())
+        dx = torch.ones(B, K, device=dev)
+        dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        dyd, xd, Wd = dy.to(dev), x.to(dev), Wt.to(dev)
+        L.check(lib.dpc_small_linear_bwd(L.ptr(dyd), L.ptr(xd), L.ptr(Wd), L.ptr(dx), L.ptr(dW), L.ptr(db), B, K, N, act, 1, L.stream()))
+        assert (dW.cpu().double() - Wr.grad).abs().max().item() < 1e-5
+        assert (dx.cpu().double() - 1 - xr.grad).abs().max().item() < 1e-5             # accumulated onto the ones
+        assert (db.cpu().double() - dy.double().sum(0)).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("L_,heads", [(32, 4), (20, 4), (64, 2)])
+def test_temporal_attention_backward(L_, heads, dev):
+    """dpc_attention_bwd_seq (rotary + relative-position bias, strided sequences) against autograd through the reference
+    formulation (...conv3d.py:311-351) in fp64: dqkv and the bias gradient."""
+    import ctypes as C
+    from diffphycon_amd import _lib as L
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import _rotary_tables
+    lib = L.lib()
+    g = torch.Generator().manual_seed(L_)
+    Bn, HW = 2, 12                                   # sequences = (b, pixel), tokens = frames at stride HW rows
+    rows = Bn * L_ * HW
+    qkv = torch.randn(rows, 3 * heads * 32, generator=g)
+    dout = torch.randn(rows, heads * 32, generator=g)
+    bias = torch.randn(heads, L_, L_, generator=g)
+    cos, sin = _rotary_tables(L_, 32)
+
+    def rot(t):                                      # t [..., L, 32]
+        t2 = t.reshape(*t.shape[:-1], 16, 2)
+        rh = torch.stack((-t2[..., 1], t2[..., 0]), -1).reshape(t.shape)
+        return t * cos.double() + rh * sin.double()
+    q0 = qkv.double().requires_grad_(True)
+    b0 = bias.double().requires_grad_(True)
+    t = q0.reshape(Bn, L_, HW, 3, heads, 32).permute(3, 0, 2, 4, 1, 5)              # [3, B, HW, heads, L, 32]
+    q, k, v = rot(t[0] * 32 ** -0.5), rot(t[1]), t[2]
+    att = torch.softmax(q @ k.transpose(-1, -2) + b0, dim=-1) @ v                     # [B, HW, heads, L, 32]
+    out = att.permute(0, 3, 1, 2, 4).reshape(rows, heads * 32)
+    out.backward(dout.double())
+    dqkv = torch.empty(rows, 3 * heads * 32, device=dev)
+    dbias = torch.full((heads, L_, L_), 1.0, device=dev)
+    ws = L.workspace(lib.dpc_attention_bwd_seq_workspace_bytes(heads, L_), dev)
+    qd, dd, cd, sd_, bd = qkv.to(dev), dout.to(dev), cos.to(dev), sin.to(dev), bias.to(dev)
+    L.check(lib.dpc_attention_bwd_seq(L.ptr(qd), L.ptr(dd), L.ptr(dqkv), L.ptr(dbias), heads, L_, Bn * HW, HW, L_ * HW, 1,
+                                      HW, L.ptr(cd), L.ptr(sd_), L.ptr(bd), 1, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    assert (dqkv.cpu().double() - q0.grad).abs().max().item() < 2e-5 * q0.grad.abs().max().item()
+    assert (dbias.cpu().double() - 1 - b0.grad).abs().max().item() < 2e-5 * b0.grad.abs().max().item()
