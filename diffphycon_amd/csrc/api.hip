@@ -42,6 +42,10 @@ static thread_local RangeCheck* g_range = nullptr;
 RangeCheck* range_check_current() { return g_range; }
 RangeCheckScope::RangeCheckScope(RangeCheck* rc) : prev_(g_range) { g_range = rc; }
 RangeCheckScope::~RangeCheckScope() { g_range = prev_; }
+static thread_local int* g_oflow = nullptr;
+int* overflow_flag_current() { return g_oflow; }
+OverflowScope::OverflowScope(int* flag) : prev_(g_oflow) { g_oflow = flag; }
+OverflowScope::~OverflowScope() { g_oflow = prev_; }
 int range_check_note(const float* a0, long long rows0, int C0, const float* a1, long long rows1, int C1, const float* in_coef,
                      long long rows_per_sample, hipStream_t s) {
     RangeCheck* rc = g_range;

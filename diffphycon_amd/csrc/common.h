@@ -83,6 +83,19 @@ int launch_range_check(const float* x, long long rows, int C, const float* in_co
                        int* flag, int id, hipStream_t s);
 int range_check_note(const float* a0, long long rows0, int C0, const float* a1, long long rows1, int C1, const float* in_coef,
                      long long rows_per_sample, hipStream_t s);
+// ALWAYS-ON activation-range sentinel of the f16x3 mode (cheap; complements the opt-in streaming RangeCheck above).  The tensors a
+// later f16x3 kernel splits WITHOUT a normalisation in front are the residual-stream tensors; each is checked where it is produced,
+// inside kernels that are not matrix-bound: the GroupNorm apply (+ residual) pass, the implicit-GEMM vector epilogue (res_conv with
+// the fused GroupNorm residual, attention output projections, down / up-sampling convolutions, split-K reduce) and the fused temporal
+// attention's store.  A value with |v| > 4094 (the documented contract of every f16x3 consumer: 65504 / 2^4) or a non-finite one ORs
+// bit 0 into this device word; dpc_unet3d_range_status reads it once per sample() -- no per-forward sync, no extra pass.
+constexpr unsigned F16X3_ACT_LIMIT_BITS = 0x457FE000u;      // 4094.0f
+int* overflow_flag_current();               // device word of the innermost OverflowScope of this thread, or null
+struct OverflowScope {
+    explicit OverflowScope(int* flag);
+    ~OverflowScope();
+    int* prev_;
+};
 const char* mode_name(int mode);
 std::string modes_string(const Modes& m);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -102,6 +115,12 @@ struct ProfScope {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// |bits| compare as unsigned: Inf / NaN patterns are larger than every finite one, so they trip the sentinel too
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ void overflow_note4(int* flag, const f32x4& v) {
+    const unsigned m = max(max(abs_bits(v[0]), abs_bits(v[1])), max(abs_bits(v[2]), abs_bits(v[3])));
+    if (flag && m > F16X3_ACT_LIMIT_BITS) atomicOr(flag, 1);
+}
 
 // ---------------------------------------------------------------- implicit GEMM (igemm.hip)
 // out[m][n] = bias[n] + resid[m][n] + sum_{tap,c} A(m,tap,c) * W(tap,c,n)
@@ -142,6 +161,7 @@ struct IgemmParams {
     const float* gn_coef;
     long long gn_rows;
     int dbg;                // debugging only (env DPC_IGEMM_DBG): 1 = scalar epilogue
+    int* oflag;             // f16x3 activation-range sentinel (filled by the launcher from overflow_flag_current(); out_mode 0 / 2 outputs)
 };
 // f16x3 weight packers raise this device flag when a weight leaves the fp16 range after its 2^12 pre-scale (|w| > 15.99);
 // dpc_unet*_finalize reads it (a host sync, at load time only) and fails loudly instead of computing with a clamped weight.
@@ -230,6 +250,7 @@ struct TattnParams {
     long long npix;         // B*HW sequences
     long long HW;
     int F;
+    int* oflag;             // tattn3 only: f16x3 activation-range sentinel for the block output (filled by its launcher)
 };
 // Fused Residual(PreNorm(SpatialLinearAttention)) (lattn_fused.hip); weights in the reference layout
 struct LattnParams {

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
                         for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
                         v += y;
                     }
+                    overflow_note4(p.oflag, v);          // f16x3 activation-range sentinel (common.h): this output may be split next
                     *reinterpret_cast<f32x4*>(p.out + orow + n) = v;
                 }
             }
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
 // second half of a split-K launch: out = (sum of the slices in index order) * 2^-16 + bias (+ residual), [M][N] layout
 __global__ __launch_bounds__(256) void igemm3_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                             const float* __restrict__ resid, float* __restrict__ out, long long MN,
-                                                            int N, int nsl, float descale) {
+                                                            int N, int nsl, float descale, int* oflag) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= MN) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(part + i);
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(256) void igemm3_reduce_kernel(const float* __restr
     v *= descale;
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int)(i % N));
     if (resid) v += *reinterpret_cast<const f32x4*>(resid + i);
+    overflow_note4(oflag, v);
     *reinterpret_cast<f32x4*>(out + i) = v;
 }
 
@@ -541,6 +543,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     if (p.act_scale == 0.f) p.act_scale = g3::SA;                    // f16x3 kernels: activation scale and its inverse x 2^-12
     p.descale = 1.0f / (p.act_scale * g3::SW);
     p.cs0 = p.a0_stride ? p.a0_stride : p.C0;
+    p.oflag = igemm_mode_default() == 2 ? overflow_flag_current() : nullptr;      // the range only exists in the f16x3 mode
     DPC_REQUIRE(p.C0 % 4 == 0 && p.C1 % 4 == 0, "igemm6: channel counts must be multiples of 4");
     DPC_REQUIRE(p.ntaps >= 1 && p.ntaps <= 32, "igemm6: 1..32 taps");
     DPC_REQUIRE(!(p.ln_stats && (p.ntaps != 1 || p.C1 != 0)), "igemm6: LayerNorm prologue needs a 1-tap single-source op");
@@ -612,7 +615,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
             DPC_LAUNCH_CHECK();
             const long long MN = p.M * p.N;
             hipLaunchKernelGGL(igemm3_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, scratch, p.bias, p.resid,
-                               p.out, MN, p.N, nsl, p.descale);
+                               p.out, MN, p.N, nsl, p.descale, p.oflag);
             DPC_LAUNCH_CHECK();
             return DPC_OK;
         }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ scale_shift, long long R, int C,
-                                                       int groups, int nblk) {
+                                                       int groups, int nblk, int* oflag) {
     __shared__ float s_mean[1024], s_rstd[1024];   // per group (groups <= 1024)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / groups;
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
     const float* rb = resid ? resid + (long long)b * R * C : nullptr;
     const long long rpb = (R + nblk - 1) / nblk;
     const long long r_begin = blockIdx.x * rpb, r_end = min(R, r_begin + rpb);
+    unsigned omx = 0;
     for (long long r = r_begin + rsub; r < r_end; r += rpp) {
         f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
 #pragma unroll
@@ -218,8 +219,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
             v[i] = y / (1.0f + expf(-y));
         }
         if (rb) v += *reinterpret_cast<const f32x4*>(rb + r * C + c4 * 4);
+        omx = max(omx, max(max(abs_bits(v[0]), abs_bits(v[1])), max(abs_bits(v[2]), abs_bits(v[3]))));
         *reinterpret_cast<f32x4*>(ob + r * C + c4 * 4) = v;
     }
+    if (oflag && omx > F16X3_ACT_LIMIT_BITS) atomicOr(oflag, 1);     // f16x3 activation-range sentinel (common.h)
 }
 
 // ---- fused-statistics path: the conv3x6 epilogue already produced per-tile channel sums (Conv3hParams::gn_part)
@@ -315,7 +318,7 @@ int launch_gn_apply(const float* x, float* out, const float* resid, const float*
     if (nblk < 1) nblk = 1;
     if (nblk > 1024) nblk = 1024;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, out, resid, stats, gamma, beta, scale_shift, R,
-                       C, groups, (int)nblk);
+                       C, groups, (int)nblk, overflow_flag_current());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
@@ -339,7 +342,7 @@ int launch_groupnorm_silu(const float* x, float* out, const float* resid, const 
                        B);
     DPC_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_apply_kernel, dim3((int)nblk, B), dim3(256), 0, s, x, out, resid, stats, gamma, beta,
-                       scale_shift, R, C, groups, (int)nblk);
+                       scale_shift, R, C, groups, (int)nblk, overflow_flag_current());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -298,11 +298,15 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
                 res[r] = PASS == 2 ? part[o] : p.x[o];      // pass 1 stores (its sum + x) into `part`: the same bits as part + x later
             }
             float* dstp = PASS == 1 ? part : p.out;
+            unsigned omx = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = rowmap3(r, hh);
-                if (FULL || i < F) dstp[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+                const float v = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+                omx = max(omx, abs_bits(v));
+                if (FULL || i < F) dstp[(row0 + (long long)i * HW) * C + nt * 32 + l31] = v;
             }
+            if (PASS != 1 && p.oflag && omx > F16X3_ACT_LIMIT_BITS) atomicOr(p.oflag, 1);     // activation-range sentinel (common.h)
         }
     }
 }
@@ -545,11 +549,15 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                     res[r] = PASS == 2 ? part[o] : p.x[o];
                 }
                 float* dstp = PASS == 1 ? part : p.out;
+                unsigned omx = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = 32 * it + rowmap3(r, hh);
-                    if (i < F) dstp[(row0 + (long long)i * HW) * C + nt * 32 + l31] = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+                    const float v = y[nt][r] * (1.f / (SO * SWGT)) + res[r];
+                    omx = max(omx, abs_bits(v));
+                    if (i < F) dstp[(row0 + (long long)i * HW) * C + nt * 32 + l31] = v;
                 }
+                if (PASS != 1 && p.oflag && omx > F16X3_ACT_LIMIT_BITS) atomicOr(p.oflag, 1);
                 asm volatile("" ::: "memory");       // keep the next column tile's residual loads behind these stores (registers)
             }
         };
@@ -620,8 +628,10 @@ static void launch_t3w(const TattnParams& p, const unsigned char* wq3, const uns
     hipLaunchKernelGGL((tattn3w_kernel<C, PASS>), dim3((unsigned)grid), dim3(256), LDS, s, p, wq3, wo3, part);
 }
 
-int launch_tattn3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, int C, void* workspace,
+int launch_tattn3(const TattnParams& p_in, const unsigned char* wq3, const unsigned char* wo3, int C, void* workspace,
                   hipStream_t s) {
+    TattnParams p = p_in;
+    p.oflag = overflow_flag_current();
     DPC_REQUIRE(tattn3_supported(C, p.F, 4), "tattn3: unsupported shape");
     DPC_REQUIRE(p.F > 32 ? p.brel != nullptr : p.bias32 != nullptr, "tattn3: bias table (padded / Toeplitz form) missing");
     DPC_REQUIRE(C == 64 || workspace, "tattn3: the C = 128 form needs its partial-sum workspace");

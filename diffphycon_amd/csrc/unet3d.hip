@@ -30,6 +30,7 @@ struct dpc_unet3d_s {
     int attn_mode = 2;           // = modes.attn: f32 (0: fused attention on the fp32 MFMA) | x6 (1: bf16x6) | f16x3 (2, default)
     dpc::RangeCheck range;       // dpc_unet3d_set_range_check: f16x3 activation range check (common.h)
     dpc::DevBuf range_flag;
+    dpc::DevBuf oflow;           // always-on f16x3 activation-range sentinel word (common.h: OverflowScope), read by dpc_unet3d_range_status
     bool fused_gn = true;        // DPC_UNFUSED_GN=1: standalone GroupNorm passes (3 per norm) instead of the conv-fused form
     // debug taps
     bool taps_on = false;
@@ -824,6 +825,12 @@ int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int
     const long long in_per = (long long)F * x_channels_total * H * W, out_per = (long long)F * h->cfg.out_dim * H * W;
     DPC_REQUIRE(!h->range.on || ((long long)H * W) % 4 == 0, "unet3d_forward: the range check needs H*W % 4 == 0");
     RangeCheckScope range_scope(h->range.on ? &h->range : nullptr);
+    const bool f16x3_any = h->modes.conv == 2 || h->modes.igemm == 2;          // the range only exists in the f16x3 mode
+    if (f16x3_any && !h->oflow.p) {
+        if (int rc = h->oflow.alloc(4)) return rc;
+        DPC_HIP(hipMemsetAsync(h->oflow.p, 0, 4, (hipStream_t)stream));
+    }
+    OverflowScope oflow_scope(f16x3_any ? reinterpret_cast<int*>(h->oflow.p) : nullptr);
     if (h->range.on) {
         h->range.names.clear();
         DPC_HIP(hipMemsetAsync(h->range_flag.p, 0x7f, 4, (hipStream_t)stream));
@@ -849,6 +856,20 @@ int dpc_unet3d_forward(dpc_unet3d_t h, const float* x, int x_channels_total, int
                                            nm + "': this arithmetic mode would clamp it; create the model with arithmetic mode x6 or f32");
         }
     }
+    return DPC_OK;
+}
+
+int dpc_unet3d_range_status(dpc_unet3d_t h, int reset, dpc_stream_t stream) {
+    DPC_REQUIRE(h, "null handle");
+    if (!h->oflow.p) return DPC_OK;
+    int v = 0;
+    DPC_HIP(hipMemcpyAsync(&v, h->oflow.p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    DPC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (v && reset) DPC_HIP(hipMemsetAsync(h->oflow.p, 0, 4, (hipStream_t)stream));
+    if (v)
+        return fail(DPC_ERR_STATE, "unet3d: an activation on the residual stream left the range the f16x3 arithmetic represents (|x| > 4094 "
+                                   "or non-finite) during a forward since the last status check: results computed from it are clamped / "
+                                   "invalid; create the model with arithmetic mode x6 or f32 (dpc_unet3d_set_range_check names the op)");
     return DPC_OK;
 }
 

@@ -307,8 +307,14 @@ class GaussianDiffusion(nn.Module):
         assert batch_size == init.shape[0]
         self._draw = _begin_noise_epoch(self)
         sample_size = (batch_size, frames, channels, image_size, image_size)
-        return sample_fn(sample_size, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low,
-                         device=device)
+        out = sample_fn(sample_size, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low,
+                        device=device)
+        # the always-on f16x3 range sentinel (include/dpc.h: dpc_unet3d_range_status): ONE host sync per sample() call -- a
+        # checkpoint whose activations leave |x| <= 4094 fails here, loudly, instead of returning clamped results
+        for m in (self.model_joint, self.model_thetas):
+            if hasattr(m, "check_range"):
+                m.check_range()
+        return out
 
 
 def _gd_trainable(self, bwd_mode="x6", loss_scale=1.0):

@@ -295,6 +295,13 @@ class Unet3D_with_Conv3D(nn.Module):
         self._ensure_handle()
         _lib.check(_lib.lib().dpc_unet3d_set_range_check(self._handle, int(enable)))
 
+    def check_range(self, reset=True):
+        """Raise if any forward since the last check produced a residual-stream activation outside the f16x3 range (|x| > 4094
+        or non-finite): the always-on sentinel of include/dpc.h dpc_unet3d_range_status.  One host sync; the samplers call it
+        once at the end of sample(), never per step."""
+        if self._handle is not None:
+            _lib.check(_lib.lib().dpc_unet3d_range_status(self._handle, int(reset), _lib.stream()))
+
     # test hook
     def debug_taps(self, enable=True):
         self._ensure_handle()

@@ -133,6 +133,16 @@ const char* dpc_unet3d_modes(dpc_unet3d_t h);
  * Costs one extra read of every conv input and one host sync per forward: a validation aid (e.g. the first run of a
  * new checkpoint), not for the timed path. */
 int dpc_unet3d_set_range_check(dpc_unet3d_t h, int enable);
+/* ALWAYS-ON range sentinel of the f16x3 mode (no extra pass, no per-forward sync): the kernels that PRODUCE the residual-stream
+ * tensors -- the only tensors a later f16x3 kernel splits without a normalisation in front (ResnetBlock / res_conv / Downsample /
+ * Upsample inputs, ...conv3d.py:206-230,159-163) -- OR a bit into a device word of the handle when an output has |x| > 4094 or is
+ * not finite (GroupNorm-apply + residual pass, implicit-GEMM vector epilogue, fused temporal attention store).
+ * dpc_unet3d_range_status reads that word (one host sync; reset != 0 clears it): DPC_OK, or DPC_ERR_STATE when any forward since
+ * the last cleared status left the range.  The Python sampler calls it once at the end of sample().  Contract of the f16x3
+ * mode, per kernel family: activations up to |x| <= 4094 are represented with 22 significant bits by EVERY kernel; beyond it the
+ * direct convolutions / implicit GEMMs / stem clamp at 4094 and the Winograd convolution stays exact up to 32752 (plain input) /
+ * 5676 (fused GroupNorm input) and then yields inf -> NaN; weights must satisfy |w| <= 15.99 (checked by dpc_unet3d_finalize). */
+int dpc_unet3d_range_status(dpc_unet3d_t h, int reset, dpc_stream_t stream);
 int dpc_unet3d_debug_taps(dpc_unet3d_t h, int enable);
 int dpc_unet3d_get_tap(dpc_unet3d_t h, const char* name, float* dst_d, size_t dst_floats, dpc_stream_t stream);
 

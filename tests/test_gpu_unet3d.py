@@ -272,6 +272,34 @@ def test_activation_outside_the_f16x3_range_fails_loudly_on_request(dev):
     assert ((y - ref).abs().max() / ref.abs().max()).item() < 1e-4
 
 
+def test_residual_stream_outside_the_f16x3_range_fails_at_the_end_of_sample(dev):
+    """The ALWAYS-ON sentinel (no opt-in range check, no extra pass): the kernels that produce residual-stream tensors flag
+    |x| > 4094; sample() raises once at its end.  A stem bias of 6000 puts the whole residual stream out of range."""
+    from oracle import unet3d as O
+    from oracle import sampler_smoke as S
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, SmokeGuidance
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+
+    def sampler(sdj, arithmetic=None):
+        mj = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=6, arithmetic=arithmetic)
+        mw = Unet3D_with_Conv3D(dim=16, dim_mults=(1, 2), channels=2, arithmetic=arithmetic)
+        mj.load_state_dict(sdj)
+        mw.load_state_dict(O.synthetic_state_dict(O.Unet3DConfig(dim=16, dim_mults=(1, 2), channels=2), seed=1))
+        return GaussianDiffusion([mj.to(dev), mw.to(dev)], image_size=16, frames=4, timesteps=3, sampling_timesteps=3, loss_type="l2",
+                                 objective="pred_noise", standard_fixed_ratio=0.01, coeff_ratio=0.0, eval_2ddpm=True, w_prob_exp=0.97,
+                                 device=dev)
+    sd = O.synthetic_state_dict(O.Unet3DConfig(dim=16, dim_mults=(1, 2), channels=6), seed=0)
+    init = torch.zeros(2, 16, 16, device=dev)
+    kw = dict(batch_size=2, design_fn=SmokeGuidance(S.RESCALER, 0.0), design_guidance="standard", init=init)
+    assert torch.isfinite(sampler(sd).sample(**kw)).all()                        # a sane net: clean, no error
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["init_conv.weight"] = bad["init_conv.weight"] * 0
+    bad["init_conv.bias"] = torch.full_like(bad["init_conv.bias"], 6000.0)
+    with pytest.raises(RuntimeError, match="left the range the f16x3 arithmetic represents"):
+        sampler(bad).sample(**kw)
+    assert torch.isfinite(sampler(bad, arithmetic="x6").sample(**kw)).all()      # the exact mode has no such range
+
+
 def test_unet3d_full_width_32_frames_vs_oracle(dev):
     """dim 64, mults (1,2,4) at the real sequence length (32 frames: the F == 32 specialisations of the fused temporal
     attention, 256-token linear attention, the big-tile convolution at two levels), reduced spatial extent 16x16."""
