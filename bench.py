@@ -75,9 +75,19 @@ def pmc_traffic(kernel_class):
     doubled per the guide's gfx950 correction, + WRITE_SIZE), or None.  Not measured by this run: PMC needs rocprofv3."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        return json.load(open(path)).get(kernel_class, {}).get("hbm_bytes_per_launch")
+        row = json.load(open(path)).get(kernel_class, {})
     except (OSError, ValueError):
         return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import source_stamp
+        stamp = source_stamp(kernel_class)
+    except Exception:
+        stamp = None
+    # counters measured on another version of the kernel's source are stale: report null rather than a wrong number
+    if row.get("kernel_source_sha16") is None or row.get("kernel_source_sha16") != stamp:
+        return None
+    return row.get("hbm_bytes_per_launch")
 
 
 def synthetic_init(batch, traj0, size=SIZE):
@@ -442,6 +452,65 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
     return out
 
 
+def run_s128_leg(ctx, args, t_start, batch=8):
+    """BASELINE.json configs[4] shape (S128: 128 x 128 x 64 frames), batch 8 per GPU, micro-batch 1: the headline step at that extent."""
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
+    gd, _ = build_models(ctx.device, 1, frames=64, size=128)
+    guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
+    gd.noise_seed, gd.traj_offset = 0, ctx.rank * batch
+    init = torch.nn.functional.interpolate(synthetic_init(batch, ctx.rank * batch)[:, None], scale_factor=2)[:, 0].to(ctx.device)
+    x = gd.sample_noise([batch, 64, 6, 128, 128], ctx.device)
+    x[:, 0, 0] = init
+    st = {"t": 999}
+
+    def step():
+        gd.p_sample(None, x, st["t"], design_fn=guide, design_guidance="standard", init=init)
+        st["t"] = st["t"] - 1 if st["t"] > 1 else 999
+    sec, sec_min, _, _, _ = timed_loop(ctx, step, args.steps, args.warmup, profile=False)
+    assert torch.isfinite(x).all()
+    ctx.log(t_start, f"s128: {sec * 1e3:.1f} ms/step")
+    return {"metric": "guided trajectories/sec, 2D smoke 128x128x64 @1000 DDPM steps", "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec),
+            "unit": "trajectories/s", "n_gpus": ctx.world, "steps": args.steps, "ms_per_step": sec * 1e3, "dtype": "f32",
+            "config": {"workload": f"S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU, micro-batch 1",
+                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
+
+
+def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
+    """BASELINE.json configs[3] (J128): jellyfish full observation, 128 x 128 x 20 frames, joint (7 -> 4) + prior (7 -> 1) video
+    U-Nets reweighted, design gradient through the two 2-D surrogates, batch 16 per GPU.  The entry script's own pipeline
+    (inference/inference_2d_jellyfish.py --synthetic) runs at two chain lengths; the difference is the per-step time."""
+    sys.path.insert(0, os.path.join(ROOT, "inference"))
+    import inference_2d_jellyfish as J
+    times = {}
+    for T in (4, 4, 20):
+        a = J.build_parser().parse_args(["--synthetic", "True", "--batch_size", str(batch), "--num_batches", "1", "--timesteps", str(T),
+                                         "--sampling_timesteps", str(T), "--image_size", str(image_size), "--frames", str(frames),
+                                         "--inference_result_path", "/tmp/dpc_bench_j128"])
+        a.device = ctx.device
+        torch.manual_seed(0)
+        J.load_normalization(a)
+        force_model, diffusion, bd_updater, design_fn = J.load_model(a)
+        ppl = J.InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": a.design_guidance, "bd_updater": bd_updater},
+                                  results_path=a.inference_result_path, args_general=a)
+        ctx.sync()
+        t0 = time.perf_counter()
+        ppl.run(J.synthetic_batches(a))
+        ctx.sync()
+        times[T] = time.perf_counter() - t0
+        del ppl, diffusion, force_model, bd_updater, design_fn
+        torch.cuda.empty_cache()
+    sec, _ = ctx.reduce((times[20] - times[4]) / 16)
+    ctx.log(t_start, f"j128: {sec * 1e3:.1f} ms per guided step")
+    return {"metric": f"guided trajectories/sec, 2D jellyfish {image_size}x{image_size}x{frames} @1000 DDPM steps",
+            "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": ctx.world,
+            "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"J128 (BASELINE.json configs[3]): 2D jellyfish full-obs {image_size}x{image_size} x {frames} "
+                                   f"frames, joint+prior Unet3D reweighted + design gradient on libdpc, batch={batch} per GPU; "
+                                   "per-step time = (20-step run - 4-step run) / 16 of the entry script's pipeline",
+                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
+
+
 def run_smoke_evaluator(ctx, B=64, T=256):
     """Post-sampling PDE evaluator: B rollouts x T frames in one launch, as multi_evaluate consumes them."""
     import numpy as np
@@ -487,7 +556,7 @@ def self_launch(args, argv):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128", "train"],
+    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128", "train", "j128"],
                     help="smoke = BASELINE.json's headline metric S64 (default); burgers = configs[1]; s128 = configs[4] shape "
                          "(128x128x64 frames; builder-side line, batch 8 per GPU by default)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -560,6 +629,17 @@ def main():
         if rank == 0:
             out.update({"warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                         "data": "synthetic", "world_size_seen_by_rccl": seen_world, "launcher": launcher})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "j128":
+        out = run_j128(ctx, args, t_start, batch=args.batch or 16)
+        if rank == 0:
+            out.update({"steps": 16, "warmup": 4, "world_size_seen_by_rccl": seen_world, "launcher": launcher, "roofline": None,
+                        "cpu_baseline": None})
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
@@ -653,6 +733,17 @@ def main():
             if rank == 0 and world == 1:
                 out["smoke_evaluator"] = run_smoke_evaluator(ctx)
                 ctx.log(t_start, "evaluator leg done")
+            # the other BASELINE configs and the training step, short legs folded into the same line
+            del gd
+            torch.cuda.empty_cache()
+            extra = argparse.Namespace(**vars(args))
+            extra.steps, extra.warmup = min(args.steps, 3), 1
+            legs = {}
+            legs["s128"] = run_s128_leg(ctx, extra, t_start)
+            legs["j128"] = run_j128(ctx, extra, t_start)
+            legs["train"] = run_train(ctx, extra, t_start, with_cpu=False)
+            if rank == 0:
+                out.update(legs)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and not s128:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, args.cpu_budget * 0.8)

@@ -59,6 +59,12 @@ int range_check_note(const float* a0, long long rows0, int C0, const float* a1, 
         if (int r = launch_range_check(a1, rows1, C1, nullptr, 0, limit, rc->flag, id, s)) return r;
     return DPC_OK;
 }
+int debug_switch(const char* name, int dflt) {
+    static const bool on = [] { const char* e = getenv("DPC_DEBUG"); return e && e[0] == '1'; }();
+    if (!on) return dflt;
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 int conv_mode_default() { return modes_current().conv; }
 int igemm_mode_default() { return modes_current().igemm; }
 }  // namespace dpc
@@ -174,13 +180,16 @@ int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, floa
         q.a0 = x_cl; q.C0 = Cin; q.wp = wp; q.bias = bias; q.out = out_cl;
         q.B = B; q.F = F; q.H = H; q.W = W; q.N = Cout; q.Npad = p.Npad; q.kchunks = (Cin + 15) / 16;
         if (conv_mode_default() == 2) {
-            if (conv3w_shape_ok(F, H, W, Cout, p.Npad) && Cin % 32 == 0) {          // Winograd pack: 36 x 64 B per (chunk, n)
+            q.wpw = wp;                                 // (probe with the launcher's OWN predicate: the two must not diverge)
+            const bool take_w = Cin % 32 == 0 && conv3w_supported(q);
+            q.wpw = nullptr;
+            if (take_w) {                               // Winograd pack: 36 x 64 B per (chunk, n)
                 int rc = launch_pack_weights_w3(w_ref, wp, Cout, p.Npad, Cin, s);
                 if (rc) return rc;
                 q.wp = nullptr; q.wpw = wp;
                 // perf attribution only (tools/bench_conv.py): DPC_CONV_FAKE_GN=1 times the fused GroupNorm+SiLU loader on a
                 // constant coefficient table (y = x + 1); the result is then NOT the convolution of x
-                static const int fake_gn = [] { const char* e = getenv("DPC_CONV_FAKE_GN"); return e ? atoi(e) : 0; }();
+                static const int fake_gn = debug_switch("DPC_CONV_FAKE_GN", 0);
                 if (fake_gn) {
                     static float* tab = nullptr;
                     static size_t cap = 0;

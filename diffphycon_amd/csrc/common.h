@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,16 @@ int fail(int code, const std::string& msg);
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// One-time, PER-DEVICE set-up guard (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: a
+// process that touches a second GPU must set it there too).  Drop-in for `static bool once`: `if (!once) { ...; once = true; }`.
+// Racing host threads may both run the block -- it is idempotent -- but neither can skip it on a device where it has not run.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool operator!() const { return !((mask.load(std::memory_order_acquire) >> dev()) & 1ull); }
+    DeviceOnce& operator=(bool v) { if (v) mask.fetch_or(1ull << dev(), std::memory_order_release); return *this; }
+};
+
 // Remainder plane of the 2-way fp16 operand split: the packed pair (f16(x0 - h.lo), f16(x1 - h.hi)) for a packed f16 pair h, as ONE
 // v_fma_mix per element (f32 * 1.0 - f16 -> f16).  x - h is exact in fp32, so this rounds exactly as convert -> subtract -> convert
 // does, in a third of the VALU instructions.
@@ -60,8 +71,10 @@ struct ModeScope {
     const Modes* prev_;
     Modes cur_;
 };
-// Opt-in activation range check of the f16x3 mode (dpc_unet*_set_range_check): the split-operand kernels clamp activations at
-// |x| > 65504 / 2^4 = 4094 (conv3f3.hip / igemm6.hip / stem7x6.hip: SA = 16).  With the check on, every f16x3 conv / implicit
+// Opt-in activation range check of the f16x3 mode (dpc_unet*_set_range_check).  Range contract per kernel family: every f16x3
+// kernel represents |x| <= 4094 with 22 significant bits; beyond it the direct convolutions / implicit GEMMs / stem (conv3f3.hip /
+// igemm6.hip / stem7x6.hip: pre-scale SA = 16) CLAMP at 65504 / 2^4 = 4094, while the Winograd convolution (conv3w.hip: no
+// pre-scale) stays exact up to 32752 (plain input) / 5676 (fused GroupNorm input) and then produces inf -> NaN.  With the check on, every f16x3 conv / implicit
 // GEMM / stem launch of a forward is preceded by a streaming pass over its input (after the fused GroupNorm+SiLU where the
 // halo staging applies one) that records the first op whose input leaves the range; the forward then FAILS instead of
 // returning a result computed from clamped activations.  Off by default (costs one extra read of every conv input).
@@ -96,6 +109,11 @@ struct OverflowScope {
     ~OverflowScope();
     int* prev_;
 };
+// A/B and attribution switches of the kernel selection (DPC_CONV3W=0, DPC_IGEMM_SPLITK=0, DPC_UNFUSED_ATTN=1, ...) are
+// DEVELOPMENT aids: they are read only when the process also sets DPC_DEBUG=1 -- a stray variable in a production environment
+// cannot change which kernels run (the arithmetic modes DPC_*_MODE are the documented, per-handle-captured setting and are not
+// gated).  Switches that make a kernel skip work (DPC_CONV_DBG) exist only in builds with -DDPC_ENABLE_CONV_DBG.
+int debug_switch(const char* name, int dflt);
 const char* mode_name(int mode);
 std::string modes_string(const Modes& m);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -560,8 +560,8 @@ __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
 
 // which tiling a launch uses: 0 = (2 x 2)-accumulator kernel on 4x4x8 tiles, 1 = 8x4x8 tiles (64-wide), 2 = big-tile kernel
 static int conv3f3_variant(int F, int H, int W, int N, int Npad) {
-    static const int big_ok = [] { const char* e = getenv("DPC_CONV3F3_BIG"); return e ? atoi(e) : 1; }();
-    static const int tall_ok = [] { const char* e = getenv("DPC_CONV3F3_TALL"); return e ? atoi(e) : 1; }();
+    static const int big_ok = debug_switch("DPC_CONV3F3_BIG", 1);
+    static const int tall_ok = debug_switch("DPC_CONV3F3_TALL", 1);
     const bool wide = Npad % 128 == 0 && N > 64;
     if (big_ok && H % 8 == 0 && W % 8 == 0 && (F % (wide ? 4 : 8) == 0 || F >= 16)) return 2;       // partial frame tiles: F >= 16 only
     if (!wide && tall_ok && F % 8 == 0) return 1;
@@ -593,17 +593,23 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     const double flops = 2.0 * M * p.N * ntap * (p.C0 + p.C1);
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + ntap * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
-    static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
+#ifdef DPC_ENABLE_CONV_DBG            // attribution builds only (tools/build_variant.py): these bits make the kernels skip work
+    static const int dbg = debug_switch("DPC_CONV_DBG", 0);
+#else
+    constexpr int dbg = 0;
+#endif
     Conv3hParams pd = p;
     pd.dbg = dbg;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
     const bool flat = p.kd == 1;                 // (1,3,3) convolution: big-tile kernel only
     DPC_REQUIRE(!flat || (p.H % 8 == 0 && p.W % 8 == 0), "conv3f3: the (1,3,3) form needs H % 8 == 0 and W % 8 == 0");
     if (conv3w_supported(pd)) return launch_conv3w(pd, s);        // Winograd F(2,3) over frames (conv3w.hip)
+    DPC_REQUIRE(p.wp, "conv3f3: the direct kernels need the plain f16x3 weight pack (only the Winograd pack was supplied, and this "
+                      "shape / operand scale does not take the Winograd kernel)");
     DPC_REQUIRE(flat || !p.gn_part || !conv3w_shape_ok(p.F, p.H, p.W, p.N, p.Npad),
                 "conv3f3: GroupNorm partial sums are laid out for the Winograd kernel but its weight pack is missing");
     const int variant = flat ? 2 : conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
-    static const int flat_c = [] { const char* e = getenv("DPC_CONV2D_LOADER_WAVES"); return e ? atoi(e) : 1; }();
+    static const int flat_c = debug_switch("DPC_CONV2D_LOADER_WAVES", 1);
     if (variant == 2 && (!flat || flat_c) && conv3f3c_supported(pd)) return launch_conv3f3c(pd, s);     // loader-wave / persistent form
     if (variant == 2) {
         const int tf = wide ? 4 : 8;
@@ -611,7 +617,7 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
         const long long grid = tiles * (p.Npad / (wide ? 128 : 64));
         DPC_REQUIRE(grid < (1ll << 31), "conv3f3: grid too large");
         const size_t lds = (size_t)(tf + (flat ? 0 : 2)) * f3b::HH8 * HWD * PST;
-        static bool once = false;
+        static DeviceOnce once;
         if (!once) {
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 10 * 12 * PST));
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 10 * 12 * PST));
@@ -621,7 +627,7 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
             DPC_HIP(hipFuncSetAttribute((const void*)conv3f3b_kernel<128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 10 * 12 * PST));
             once = true;
         }
-        static const int persist = [] { const char* e = getenv("DPC_CONV3F3_PERSIST"); return e ? atoi(e) : 0; }();
+        static const int persist = debug_switch("DPC_CONV3F3_PERSIST", 0);
         static int ncu = 0;
         if (!ncu) {
             int dev = 0;

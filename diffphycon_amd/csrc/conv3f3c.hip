@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
 }
 
 bool conv3f3c_supported(const Conv3hParams& p) {
-    static const int ok = [] { const char* e = getenv("DPC_CONV3F3C"); return e ? atoi(e) : 1; }();
+    static const int ok = debug_switch("DPC_CONV3F3C", 1);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     const int tf = wide ? 4 : 8;
     return ok && p.H % 8 == 0 && p.W % 8 == 0 && p.N % 64 == 0 && p.N == p.Npad && (p.F % tf == 0 || p.F >= 16) &&
@@ -370,7 +370,7 @@ int launch_conv3f3c(const Conv3hParams& p, hipStream_t s) {
     const long long nwg = tiles * (p.Npad / (wide ? 128 : 64));
     DPC_REQUIRE(nwg < (1ll << 31), "conv3f3c: too many tiles");
     static int ncu = 0;
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         int dev = 0;
         hipDeviceProp_t prop;

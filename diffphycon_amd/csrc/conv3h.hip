@@ -257,7 +257,7 @@ int launch_conv3h(const Conv3hParams& p, hipStream_t s) {
     ProfScope prof(wide ? PROF_CONV3H128 : PROF_CONV3H64, flops, bytes, s);
     // weights: BN=128 reads fragments straight from L2 (keeps LDS at 34.5 KB -> 4 workgroups/CU by LDS); BN=64 stages
     // them through LDS.  Both variants measure the same throughput; DPC_CONV3H_BDIRECT=0/1 forces one (A/B tests).
-    static const int bforce = [] { const char* e = getenv("DPC_CONV3H_BDIRECT"); return e ? atoi(e) : -1; }();
+    static const int bforce = debug_switch("DPC_CONV3H_BDIRECT", -1);
     const int bdirect = bforce >= 0 ? bforce : (wide ? 1 : 0);
     if (wide) {
         const long long grid = tiles * (p.Npad / 128);

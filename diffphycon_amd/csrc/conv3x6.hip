@@ -859,7 +859,11 @@ int launch_conv3x6(const Conv3hParams& p, hipStream_t s) {
     const double flops = 2.0 * M * p.N * 27.0 * (p.C0 + p.C1);
     const double bytes = 4.0 * (M * p.N + M * (p.C0 + p.C1) + 27.0 * (p.C0 + p.C1) * p.N);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
-    static const int dbg = [] { const char* e = getenv("DPC_CONV_DBG"); return e ? atoi(e) : 0; }();
+#ifdef DPC_ENABLE_CONV_DBG            // attribution builds only (tools/build_variant.py): these bits make the kernels skip work
+    static const int dbg = debug_switch("DPC_CONV_DBG", 0);
+#else
+    constexpr int dbg = 0;
+#endif
     Conv3hParams pd = p;
     pd.dbg = dbg;
     return launch_conv3x6_impl(pd, wide, tiles, flops, bytes, s);
@@ -868,8 +872,8 @@ int launch_conv3x6(const Conv3hParams& p, hipStream_t s) {
 int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, double flops, double bytes, hipStream_t s) {
     using namespace x6;
     ProfScope prof(wide ? PROF_CONV3X6_128 : PROF_CONV3X6_64, flops, bytes, s);
-    static const int bdirect = [] { const char* e = getenv("DPC_CONV3X6_BDIRECT"); return e ? atoi(e) : 3; }();   // 0 LDS weights, 1 direct, 2 pipelined direct (BN=64 only), 3 pipelined direct for both widths (default), 4 hand-counted vmcnt
-    static const int tall = [] { const char* e = getenv("DPC_CONV3X6_TALL"); return e ? atoi(e) : 0; }();   // measured = v2, kept opt-in
+    static const int bdirect = debug_switch("DPC_CONV3X6_BDIRECT", 3);   // 0 LDS weights, 1 direct, 2 pipelined direct (BN=64 only), 3 pipelined direct for both widths (default), 4 hand-counted vmcnt
+    static const int tall = debug_switch("DPC_CONV3X6_TALL", 0);   // measured = v2, kept opt-in
     const bool fused_gn = p.gn_part || p.in_coef;          // only the default kernels implement the GroupNorm fusion
     DPC_REQUIRE(!(p.in_coef && p.C1 != 0), "conv3x6: fused input normalisation needs a single source");
     if (tall && !wide && p.F >= 8 && !fused_gn) {
@@ -879,13 +883,13 @@ int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, doubl
         const long long grid = tiles8 * (p.Npad / 64);
         DPC_REQUIRE(grid < (1ll << 31), "conv3x6: grid too large");
         const size_t lds = (size_t)NSLOT8 * PST;
-        static bool once = false;
+        static DeviceOnce once;
         if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
         hipLaunchKernelGGL(conv3x6t_kernel, dim3((unsigned)grid), dim3(256), lds, s, p);
         DPC_LAUNCH_CHECK();
         return DPC_OK;
     }
-    static const int persistent = [] { const char* e = getenv("DPC_CONV3X6_PERSISTENT"); return e ? atoi(e) : 0; }();
+    static const int persistent = debug_switch("DPC_CONV3X6_PERSISTENT", 0);
     if (persistent && !wide && p.kchunks >= 1 && !fused_gn) {
         DPC_REQUIRE(p.Npad % 64 == 0, "conv3x6: Npad must be a multiple of 64");
         const long long nitems = tiles * (p.Npad / 64);
@@ -913,7 +917,7 @@ int launch_conv3x6_impl(const Conv3hParams& p, bool wide, long long tiles, doubl
             hipLaunchKernelGGL((conv3x6_kernel<128, 1>), dim3((unsigned)grid), dim3(256), (size_t)NSLOT * PST, s, p);
         } else {
             const size_t lds = (size_t)NSLOT * PST + 2 * 128 * PST;
-            static bool once = false;
+            static DeviceOnce once;
             if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)conv3x6_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
             hipLaunchKernelGGL((conv3x6_kernel<128, 0>), dim3((unsigned)grid), dim3(256), lds, s, p);
         }

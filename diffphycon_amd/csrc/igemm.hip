@@ -215,14 +215,14 @@ int launch_igemm(const IgemmParams& p_in, hipStream_t s) {
     if (p.Npad % 128 == 0 && p.N > 64) {
         const int grid = mtiles * (p.Npad / 128);
         const size_t lds = 2 * (BM + 128) * LDS_STRIDE * sizeof(float);
-        static bool once = false;
+        static DeviceOnce once;
         if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)igemm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
         hipLaunchKernelGGL(igemm_kernel<128>, dim3(grid), dim3(256), lds, s, p);
     } else {
         DPC_REQUIRE(p.Npad % 64 == 0, "igemm: Npad must be a multiple of 64");
         const int grid = mtiles * (p.Npad / 64);
         const size_t lds = 2 * (BM + 64) * LDS_STRIDE * sizeof(float);
-        static bool once = false;
+        static DeviceOnce once;
         if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)igemm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
         hipLaunchKernelGGL(igemm_kernel<64>, dim3(grid), dim3(256), lds, s, p);
     }
@@ -353,7 +353,7 @@ int launch_stem(const StemParams& p, hipStream_t s) {
     const int grid = mtiles * (p.Npad / 64);
     const size_t lds = 2 * (BM + 64) * LDS_STRIDE * sizeof(float);
     ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * p.kchunks * 32, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
     hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), lds, s, p);
     DPC_LAUNCH_CHECK();

@@ -581,7 +581,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     // so that the launch still covers the 256 CUs at least twice
     // 64-wide tiles at four workgroups per CU beat the 128-wide tile (two per CU) on every shape of both workloads
     // (smoke 31.4 -> 24.9 ms/step, Burgers 24.2 -> 22.0): DPC_IGEMM_WIDE=1 re-enables the wide tile for A/B runs
-    static const int wide_ok = [] { const char* e = getenv("DPC_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
+    static const int wide_ok = debug_switch("DPC_IGEMM_WIDE", 0);
     const bool wide = wide_ok && !p.gn_raw && p.Npad % 128 == 0 && p.N > 64 && (long long)mtiles * (p.Npad / 128) >= 512;
     ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
     if (igemm_mode_default() == 2) {
@@ -591,7 +591,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
         // separate workgroups, a second kernel adds them in fixed order.  The rule looks at the reduction length only, never
         // at the batch, so a trajectory's result does not depend on how the batch is sharded or micro-batched.  The scratch
         // buffer is grown on first use (warm-up), never inside a steady-state step.
-        static const int split_ok = [] { const char* e = getenv("DPC_IGEMM_SPLITK"); return e ? atoi(e) : 1; }();
+        static const int split_ok = debug_switch("DPC_IGEMM_SPLITK", 1);
         const long long nwg = (long long)mtiles * (p.Npad / 64);
         const int nit = p.ntaps * p.kchunks;
         int nsl = 1;

@@ -335,7 +335,7 @@ int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned
     const double rows = (double)p.images * p.N;
     ProfScope prof(PROF_LATTN_FUSED, 2.0 * rows * C * 384 + 4.0 * rows * 32 * 32 * 4 + 2.0 * rows * 128 * C,
                    4.0 * rows * C * 3, s);
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<64>::LDS_BYTES));
         DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<128>::LDS_BYTES));

@@ -629,7 +629,7 @@ static int smoke_prepare(const dpc_smoke_domain* dom, int B, void* ws, size_t ws
 static int smoke_launch(SmokeParams& P, int B, hipStream_t s) {
     const size_t lds = smoke_lds_bytes(P.N);
     DPC_REQUIRE(lds <= 160 * 1024, "smoke: grid too large for the 160 KB LDS");
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)smoke_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DPC_HIP(hipFuncSetAttribute((const void*)smoke_cg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

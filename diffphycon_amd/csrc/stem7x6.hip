@@ -229,7 +229,7 @@ size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }      /
 static bool stem_h3() { return modes_current().stem != 1; }
 // 4-channel slots (half the MFMAs) for stems of at most 4 input channels in the f16x3 form; DPC_STEM_CS4=0 keeps the 8-channel form
 static bool stem_cs4(int C) {
-    static const int ok = [] { const char* e = getenv("DPC_STEM_CS4"); return e ? atoi(e) : 1; }();
+    static const int ok = debug_switch("DPC_STEM_CS4", 1);
     return ok && C <= 4 && stem_h3();
 }
 
@@ -245,7 +245,7 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     const bool h3 = stem_h3(), cs4 = stem_cs4(p.C);
     const size_t lds = cs4 ? (size_t)PLANEB : (h3 ? 2 : 3) * (size_t)PLANEB;       // (4-channel slots: 2 planes of half the size)
     ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * 343.0 * p.C, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PLANEB));
         DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PLANEB));

@@ -437,14 +437,17 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ y,
 
 // out[0] = max(out[0], max |x|)   (bit pattern of a non-negative float orders like an unsigned integer)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ out, long long total4) {
-    float m = 0.f;
+    // maximum over the |bits| as unsigned integers: identical to the float maximum for finite values, and Inf / NaN patterns
+    // (>= 0x7f800000) win against every finite one -- a non-finite gradient PROPAGATES into the result instead of being dropped by
+    // fmaxf, so the caller's isfinite() guard sees it
+    unsigned m = 0;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        m = max(max(m, max(abs_bits(v.x), abs_bits(v.y))), max(abs_bits(v.z), abs_bits(v.w)));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 static inline unsigned grid_for(long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 256 * 16); }
@@ -699,7 +702,7 @@ int dpc_linear_attention_bwd(const float* qkv, const float* dout, float* dqkv, i
     ProfScope prof(PROF_LINATTN, 8.0 * rows_ * 32 * 32 * heads, 4.0 * rows_ * heads * 32 * 10, s);
     hipLaunchKernelGGL(linattn_bwd_ctx_kernel, dim3((unsigned)(images * heads)), dim3(256), 0, s, qkv, dout, w, heads, N);
     DPC_LAUNCH_CHECK();
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)linattn_bwd_tok_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LAB_LDS));
         once = true;
@@ -715,7 +718,7 @@ int dpc_attention_bwd(const float* qkv, const float* dout, float* dqkv, int head
     if (images == 0) return DPC_OK;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)4 * L * 33 + 3 * L) * sizeof(float);
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 256 * 33 + 3 * 256) * 4));
         once = true;

@@ -606,7 +606,7 @@ template <int C, int PASS>
 static void launch_t3(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, float* part, long long grid,
                       hipStream_t s) {
     constexpr int LDS = T3<C>::LDS_BYTES;
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         (void)hipFuncSetAttribute((const void*)tattn3_kernel<C, true, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)tattn3_kernel<C, false, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -620,7 +620,7 @@ template <int C, int PASS>
 static void launch_t3w(const TattnParams& p, const unsigned char* wq3, const unsigned char* wo3, float* part, long long grid,
                        hipStream_t s) {
     constexpr int LDS = T3W<C>::LDS_BYTES;
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         (void)hipFuncSetAttribute((const void*)tattn3w_kernel<C, PASS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         once = true;

@@ -269,7 +269,7 @@ int launch_tattn6(const TattnParams& p, const unsigned char* wq6, const unsigned
                    4.0 * rows * C * 2, s);
     const size_t lds = (size_t)(3 * (C / 16) * 3 + (C / 32) * 2 * 3) * 1024;
     DPC_REQUIRE(p.bias32, "tattn6: padded bias table missing");
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)tattn6_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
         DPC_HIP(hipFuncSetAttribute((const void*)tattn6_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));

@@ -201,7 +201,7 @@ int launch_tattn_fused(const TattnParams& p, int C, hipStream_t s) {
     if (C == 64) {
         hipLaunchKernelGGL(tattn_fused_kernel<64>, dim3((unsigned)grid), dim3(256), lds, s, p);
     } else {
-        static bool once = false;
+        static DeviceOnce once;
         if (!once) { DPC_HIP(hipFuncSetAttribute((const void*)tattn_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); once = true; }
         hipLaunchKernelGGL(tattn_fused_kernel<128>, dim3((unsigned)grid), dim3(256), lds, s, p);
     }

@@ -831,7 +831,7 @@ int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, floa
     DPC_REQUIRE(!dbias || (ws && ws_bytes >= dpc_attention_bwd_seq_workspace_bytes(heads, L)), "attention_bwd_seq: workspace too small");
     if (n_seq == 0) return DPC_OK;
     hipStream_t s = (hipStream_t)stream;
-    static const int use_mfma = [] { const char* e = getenv("DPC_TATTN_BWD_MFMA"); return e ? atoi(e) : 1; }();
+    static const int use_mfma = debug_switch("DPC_TATTN_BWD_MFMA", 1);
     if (L <= 32 && use_mfma) {
         // one wave per (sequence, head); waves-per-head partial slots for the bias gradient (<= 512 as the workspace is sized)
         long long waves = std::min<long long>((n_seq * heads + 3) / 4 * 4, 256 * 4);
@@ -845,7 +845,7 @@ int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, floa
         q.waves_per_head = (int)(waves / heads);
         DPC_REQUIRE(q.waves_per_head <= 512, "attention_bwd_seq: too many heads for the bias-gradient workspace");
         const size_t lds = (size_t)4 * 5 * 32 * 33 * sizeof(float);
-        static bool once_m = false;
+        static DeviceOnce once_m;
         if (!once_m) {
             DPC_HIP(hipFuncSetAttribute((const void*)tattn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             once_m = true;
@@ -872,7 +872,7 @@ int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, floa
     p.token_stride = token_stride_rows; p.rot_cos = rot_cos; p.rot_sin = rot_sin; p.bias = bias;
     p.dbias_part = dbias ? reinterpret_cast<float*>(align_up((size_t)ws, 256)) : nullptr;
     const size_t lds = ((size_t)G * (4 * LP * 33 + 3 * LP) + 2 * LP * 32) * sizeof(float);     // (>= the [G][LP][LP + 1] reduction area)
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)tattn_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DPC_HIP(hipFuncSetAttribute((const void*)tattn_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

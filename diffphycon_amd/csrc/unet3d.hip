@@ -155,7 +155,7 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
 }
 
 bool conv_can_fuse_gn_residual(const PackedConv& pc, long long rows_per_sample) {
-    static const int ok = [] { const char* e = getenv("DPC_FUSE_GN_RES"); return e ? atoi(e) : 1; }();
+    static const int ok = debug_switch("DPC_FUSE_GN_RES", 1);
     return ok && !pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && pc.N % 4 == 0 && rows_per_sample % 128 == 0;
 }
 
@@ -210,7 +210,7 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         }
         return launch_conv3h(q, s);
     }
-    static const int flat_ok = [] { const char* e = getenv("DPC_CONV2D_HALO"); return e ? atoi(e) : 1; }();
+    static const int flat_ok = debug_switch("DPC_CONV2D_HALO", 1);
     if (flat_ok && pc.flat3 && !a0_stride && !resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo && Hi % 8 == 0 && Wi % 8 == 0 &&
         C0 % 4 == 0 && C1 % 4 == 0) {
         // (1,3,3) convolution on the halo-tile kernel: frames = the BF images (no coupling), shape-only rule (any batch size)
@@ -641,8 +641,8 @@ int dpc_unet3d_create(const dpc_unet3d_cfg* cfg, dpc_unet3d_t* out) {
     h->cfg = *cfg;
     h->modes = modes_global();
     h->attn_mode = h->modes.attn;
-    if (const char* e = getenv("DPC_UNFUSED_ATTN")) h->fused_attn = !(e[0] == '1');
-    if (const char* e = getenv("DPC_UNFUSED_GN")) h->fused_gn = !(e[0] == '1');
+    h->fused_attn = !debug_switch("DPC_UNFUSED_ATTN", 0);
+    h->fused_gn = !debug_switch("DPC_UNFUSED_GN", 0);
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
     for (int i = 0; i < cfg->n_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);

@@ -266,7 +266,7 @@ size_t wgrad3_workspace_bytes(int C, int N, long long planes) {
 
 template <int W>
 static int launch_w(const Wgrad3Params& p, int nblocks, hipStream_t s) {
-    static bool once = false;
+    static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3Cfg<W>::TOTAL));
         once = true;

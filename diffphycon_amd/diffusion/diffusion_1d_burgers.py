@@ -145,9 +145,10 @@ class GaussianDiffusion(nn.Module):
             raise NotImplementedError("the HIP path implements the 2-D conv (temporal=True, use_conv2d=True) sampler "
                                       "that get_2d_ddpm builds (train_1d_burgers.py:145-168)")
         assert type(seq_length) is tuple and len(seq_length) == 2, "should be a tuple of (Nt, Nx)"
-        if auto_normalize or conditioned_on_residual is not None or expand_condition or is_model_w or recurrence:
-            raise NotImplementedError("auto_normalize / residual conditioning / expand_condition / is_model_w / recurrence "
+        if auto_normalize or conditioned_on_residual is not None or expand_condition or is_model_w:
+            raise NotImplementedError("auto_normalize / residual conditioning / expand_condition / is_model_w "
                                       "are not used by the DiffPhyCon inference scripts")
+        self.recurrence, self.recurrence_k = bool(recurrence), int(recurrence_k)                  # (:353-354)
         assert objective == "pred_noise", "the Burgers sampler implements pred_noise"
         self.temporal, self.conv2d, self.traj_size = True, True, seq_length
         self.objective = objective
@@ -354,20 +355,65 @@ class GaussianDiffusion(nn.Module):
         x_w = torch.empty_like(img) if self.eval_two_models else None
         pingpong = torch.empty_like(img) if (guide is not None and guide.wreg != 0) else None
         for t in reversed(range(0, self.num_timesteps)):
-            self._prepare(img, x_w, u0, uT)
-            e_uw, e_w = self._denoise_step(img, x_w, t)
-            z = self.sample_noise(list(shape), device) if t > 0 else None
-            coef = self._coef(t, guide, J_sched, w_sched, clip, B)
-            if pingpong is None:
-                self._update(img, e_uw, e_w, z, tgt, img, coef)
-            else:
-                self._update(img, e_uw, e_w, z, tgt, pingpong, coef)
-                img, pingpong = pingpong, img
+            for _k in range(self.recurrence_k):                  # (:535) one pass unless --recurrence
+                self._prepare(img, x_w, u0, uT)
+                e_uw, e_w = self._denoise_step(img, x_w, t)
+                z = self.sample_noise(list(shape), device) if t > 0 else None
+                coef = self._coef(t, guide, J_sched, w_sched, clip, B)
+                if pingpong is None:
+                    self._update(img, e_uw, e_w, z, tgt, img, coef)
+                else:
+                    self._update(img, e_uw, e_w, z, tgt, pingpong, coef)
+                    img, pingpong = pingpong, img
+                if not self.recurrence:
+                    break
+                img.copy_(self.recurrent_sample(img, t))         # (:578-582) self recurrence: add the noise of level t back
         return img                                  # unnormalize = identity (auto_normalize=False, train_1d_burgers.py:148)
 
+    @torch.no_grad()
+    def recurrent_sample(self, x_tm1, t: int):
+        """(:472-482) x_t = sqrt(a_t / a_{t-1}) x_{t-1} + sqrt(1 - a_t / a_{t-1}) z with the per-step alphas (a_{-1} = 1);
+        no noise at t == 0.  Elementwise on the device; the noise is the sampler's counter-based stream."""
+        ratio = self.alphas[t] / self.alphas_prev[t]                                              # fp32 host scalars, as extract() reads
+        xtm1_coef, noise_coef = torch.sqrt(ratio), torch.sqrt(1 - ratio)
+        if t > 0:
+            return xtm1_coef.item() * x_tm1 + noise_coef.item() * self.sample_noise(list(x_tm1.shape), x_tm1.device)
+        return xtm1_coef.item() * x_tm1
+
+    @torch.no_grad()
     def ddim_sample(self, shape, return_all_timesteps=False, **kwargs):
-        raise NotImplementedError("Burgers DDIM applies no guidance and rejects the two-model sampler in the reference "
-                                  "(diffusion_1d_burgers.py:616-620); the inference scripts run DDPM (--using_ddim False)")
+        """(:587-644) the reference's Burgers DDIM: single model only (it asserts eval_two_models == False), NO guidance,
+        clip_x_start + rederived noise; conditioning / zero-fill per step as in the DDPM loop."""
+        assert not self.eval_two_models, "ddim_sample: the reference asserts eval_two_models == False (:618)"
+        if return_all_timesteps:
+            raise NotImplementedError("return_all_timesteps is not used by the scripts")
+        device, total, S, eta = self.betas.device, self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        times = list(reversed(torch.linspace(-1, total - 1, steps=S + 1).int().tolist()))
+        u0 = kwargs["u_init"].to(device=device, dtype=torch.float32).contiguous() if self.is_condition_u0 else None
+        uT = kwargs["u_final"].to(device=device, dtype=torch.float32).contiguous() if self.is_condition_uT else None
+        ac = self._host["alphas_cumprod"]
+        img = self.sample_noise(list(shape), device)
+        B = shape[0]
+        h = self._host
+        x0, scratch = torch.empty_like(img), torch.empty_like(img)
+        for time, time_next in zip(times[:-1], times[1:]):
+            self._prepare(img, None, u0, uT)
+            e_uw, _ = self._denoise_step(img, None, time)
+            # x_start = clip(c1 x - c2 eps) from the fused kernel (no guidance: model_predictions is called without nablaJ, :620);
+            # the DDIM combination itself is three elementwise passes over a [B, 2, 16, 128] tensor, done with device tensor ops
+            # (the reference's Burgers DDIM is unguided and rejected by the two-model sampler: not a hot path)
+            self._update(img, e_uw, None, None, None, scratch, self._coef(time, None, None, None, True, B), x0)
+            if time_next < 0:
+                img.copy_(x0)
+                continue
+            c1, c2 = h["sqrt_recip_alphas_cumprod"][time].item(), h["sqrt_recipm1_alphas_cumprod"][time].item()
+            pred_noise = (c1 * img - x0) / c2                                                     # rederive_pred_noise (:438-439)
+            alpha, alpha_next = ac[time], ac[time_next]
+            sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            cc = (1 - alpha_next - sigma ** 2).sqrt()
+            z = self.sample_noise(list(shape), device)
+            img.copy_(x0 * alpha_next.sqrt().item() + cc.item() * pred_noise + float(sigma) * z)
+        return img
 
     @torch.no_grad()
     def sample(self, batch_size=16, clip_denoised=True, **kwargs):

@@ -1,9 +1,11 @@
 """The two learned 2-D surrogates of the jellyfish task, with the reference's constructor and state_dict layout
 (/root/reference/diffusion/diffusion_2d_jellyfish.py: `Unet` :276-403 boundary updater, `ForceUnet` :406-481).
 
-These nets sit INSIDE the guidance gradient (inference_2d_jellyfish.py:85-114 differentiates through both), so they
-need autograd; SURVEY.md 8a-C2 / 8f-2 keeps them on stock PyTorch-ROCm ops in this build (hand-written backward
-kernels are the ranked 'next' row).  They are small next to the two space-time U-Nets (which run on libdpc)."""
+These nets sit INSIDE the guidance gradient (inference_2d_jellyfish.py:85-114 differentiates through both).  The sampler does
+NOT run these modules: since r02 the design gradient is computed by `model/surrogates_hip.py` (forward and input-gradient backward
+of both nets on libdpc kernels, no autograd).  The stock-torch modules below remain as the checkpoint CONTAINER (same
+state_dict keys as the reference, `HipUnet` / `HipForceUnet` read their weights from them) and as the test reference the HIP
+path is compared with (tests/test_gpu_surrogates_hip.py)."""
 import math
 
 import torch

@@ -82,7 +82,10 @@ class _Conv:
             m = torch.zeros(1, device=a0.device)
             _lib.check(_lib.lib().dpc_absmax(_lib.ptr(a0), a0.numel(), _lib.ptr(m), _lib.stream()))
             m = max_scalar_over_ranks(float(m.item()), a0.device)          # same scales on every rank as one process would pick
-            if m > 0 and math.isfinite(m):
+            if not math.isfinite(m):
+                raise RuntimeError("design gradient: a backward tensor of the surrogate nets is not finite (Inf / NaN reached the "
+                                   "range calibration of a backward-data convolution)")
+            if m > 0:
                 self.act_scale = 2.0 ** max(-100, min(100, round(math.log2(_Calibration.target / m))))
             _Calibration.seen.append((m, self.act_scale))
         if out is None:

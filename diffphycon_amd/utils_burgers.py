@@ -94,9 +94,9 @@ def synthetic_targets(idx, device, seed=0):
 
 def get_target(target_i, f=False, device=0, dataset="free_u_f_1e5", synthetic=False,
                partially_observed_fill_zero_unobserved=None, **dataset_kwargs):
-    """utils.py:1353-1395.  Returns the UNRESCALED target states [B, 11, 128] (or the forces with f=True).  The real
-    split is an HDF5 file read through h5py (dataset/apps/burgers_h5py.py:206-255), which this image does not ship:
-    without it only `synthetic=True` is available."""
+    """utils.py:1353-1395.  Returns the UNRESCALED target states [B, 11, 128] (or the forces [B, 10, 128] with f=True) of the
+    test split through `Burgers1D` (dataset/data_1d.py).  The split is an HDF5 file (dataset/apps/burgers_h5py.py:206-255): the
+    file open needs h5py, which this image does not ship -- then `synthetic=True`, or a `dataset_cache=BurgersCache(...)`."""
     if isinstance(device, int):       # the reference's default `device=0`: here the rank's current GPU (one process per GPU)
         dev = torch.device("cuda", torch.cuda.current_device() if device == 0 and torch.cuda.is_available() else device)
     else:
@@ -106,11 +106,15 @@ def get_target(target_i, f=False, device=0, dataset="free_u_f_1e5", synthetic=Fa
             raise NotImplementedError("synthetic targets carry no reference forces")
         u = synthetic_targets(target_i, dev)
     else:
-        try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise RuntimeError(f"reading data/{dataset} needs h5py (not installed); use --synthetic True") from e
-        raise NotImplementedError("HDF5 Burgers reader: SURVEY.md 8(f-3) 'next' row")
+        from .dataset.data_1d import Burgers1D
+        # utils.py:1357-1370: the test split through Burgers1D with rescaler 1 (the file open needs h5py and says so if missing)
+        ds = Burgers1D(dataset="burgers", input_steps=1, output_steps=10, time_interval=1, is_y_diff=False, split="test",
+                       transform=None, pre_transform=None, verbose=False, root_path=f"data/{dataset}", device="cuda", rescaler=1,
+                       nt_total=11, partially_observed_fill_zero_unobserved=partially_observed_fill_zero_unobserved,
+                       **dataset_kwargs)                    # (dataset_cache=BurgersCache(...) bypasses the HDF5 file open)
+        idx = [target_i] if isinstance(target_i, int) else list(target_i)
+        rows = torch.stack(tuple(ds.get(i) for i in idx), dim=0)
+        return (rows[:, 11:, :] if f else rows[:, :11, :]).to(dev)
     if partially_observed_fill_zero_unobserved == "front_rear_quarter":
         nx = u.shape[-1]
         u[..., nx // 4: (nx * 3) // 4] = 0

@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# libdpc reads its A/B kernel-selection switches (DPC_UNFUSED_ATTN, ...) only in processes that also set DPC_DEBUG=1 (csrc/common.h:
+# debug_switch); a few GPU tests compare the fused kernels with their unfused compositions through those switches
+os.environ.setdefault("DPC_DEBUG", "1")
 
 
 def pytest_configure(config):

@@ -40,3 +40,14 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "2"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stdout + p.stderr)
+
+
+def test_self_launch_eight_ranks_as_the_driver_does():
+    """The node-level configuration the driver measures (N = 8, one rank per GPU): 8 gloo ranks, global batch 8 x 64 = 512, one
+    JSON line from rank 0, max / min over the ranks (rank r sleeps 2 (1 + r) ms: the slowest, rank 7, sets the step time; the
+    closing barrier is inside the timed region, so every rank's elapsed time is that of the slowest)."""
+    out = _run(["--gpus", "8"])
+    assert out["n_gpus"] == 8 and out["world_size_seen_by_backend"] == 8
+    assert out["config"]["global_batch"] == 512
+    assert out["ms_per_step"] >= 15.9 and out["ms_per_step_min_rank"] <= out["ms_per_step"]
+    assert abs(out["value"] - 512 / (1000 * out["ms_per_step"] * 1e-3)) < 1e-9

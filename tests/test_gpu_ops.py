@@ -93,6 +93,27 @@ def test_conv3d_cl(case, dev, L):
     assert relerr(got, ref) < 3e-6, relerr(got, ref)
 
 
+@pytest.mark.parametrize("scale", [1e-3, 3e-2, 100.0])
+def test_conv3d_winograd_small_and_large_inputs(scale, dev, L):
+    """The Winograd kernel splits a plain (un-normalised) input WITHOUT the 2^4 pre-scale of the direct kernels: for |x| ~ 1e-3 the
+    remainder plane sits in fp16's subnormals.  The fp32 accumulation still dominates: the same 3e-6-of-range bound must hold
+    for activations of magnitude 1e-3, 3e-2 and 100."""
+    B, Fr, H, W, Ci, Co = 1, 8, 16, 16, 64, 64
+    g = torch.Generator().manual_seed(int(scale * 1000) + 5)
+    x = torch.randn(B, Ci, Fr, H, W, generator=g) * scale
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) / (Ci * 27) ** 0.5
+    b = torch.randn(Co, generator=g) * scale
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1).float()
+    xd, wd, bd = to_cl(x).to(dev), w.to(dev).contiguous(), b.to(dev)
+    out = torch.empty(to_cl(ref).shape, device=dev)
+    ws = L.workspace(L.lib().dpc_conv_workspace_bytes(Ci, Co, 27), dev)
+    L.check(L.lib().dpc_conv3d_cl(L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), B, Fr, H, W, Ci, Co, 3, 3, 3, 1, 1, 1, 1, 1, 1,
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    err = relerr(to_cf(out.cpu()), ref)
+    print(f"conv3w input scale {scale:g}: relative error {err:.3e}")
+    assert err < 3e-6, (scale, err)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_conv3d_winograd_random_shapes(seed, dev, L):
     """Random shapes inside the Winograd kernel's domain (conv3w.hip: 3x3x3, H % 8 == 0, W % 8 == 0, Cin % 32 == 0, Cout % 64 == 0, F % 4 == 0

@@ -26,8 +26,35 @@ CLASSES = [
     (r"lattn(3|6?_(ctx|out))_kernel", "linear_attention_fused"), (r"gn_(partial|finalize|finalize_fused|apply)_kernel", "groupnorm_silu"),
     (r"ln_stats_kernel", "ln_stats"), (r"ddpm_update_smoke_kernel", "ddpm_update"),
     (r"philox_normal_kernel", "philox_normal"), (r"attention_kernel", "attention_core"),
+    (r"wgrad3_kernel", "conv3_wgrad_f16x3"), (r"wgrad_kernel", "conv_wgrad"), (r"tattn_bwd", "attention_bwd"),
     (r"unet2d|conv2d", "unet2d"), (r"cg_|pressure|advect|smoke_", "smoke_rollout"), (r"burgers", "burgers"),
 ]
+
+
+# profile class -> the kernel source file(s) whose code its default-mode launches run: the traffic numbers are stamped with a hash
+# of these files and bench.py reports `traffic: null` when the stamp no longer matches the tree (a changed kernel = stale counters)
+SOURCES = {
+    "conv3x6_bn64": ["conv3w.hip", "conv3f3c.hip"], "conv3x6_bn128": ["conv3w.hip", "conv3f3c.hip"], "igemm_bn64": ["igemm6.hip"],
+    "igemm_bn128": ["igemm6.hip"], "stem_gather": ["stem7x6.hip"], "temporal_attention_fused": ["tattn3.hip"],
+    "linear_attention_fused": ["lattn3.hip"], "groupnorm_silu": ["norm.hip"], "ln_stats": ["norm.hip"], "attention_core": ["attn.hip"],
+    "ddpm_update": ["update.hip"], "conv3_wgrad_f16x3": ["wgrad3.hip"], "conv_wgrad": ["train.hip"], "attention_bwd": ["train.hip"],
+}
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "diffphycon_amd", "csrc")
+
+
+def source_stamp(cls):
+    """sha256[:16] over the kernel source files of a profile class (None for classes without a mapping)."""
+    import hashlib
+    files = SOURCES.get(cls)
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        try:
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
 
 
 def classify(name):
@@ -88,14 +115,15 @@ def main():
         wk, wn = write.get(cls, [0.0, 0])
         n = max(fn, wn, 1)
         out[cls] = {"launches": n, "fetch_kb_raw_per_launch": fk / max(fn, 1), "write_kb_raw_per_launch": wk / max(wn, 1),
-                    "hbm_bytes_per_launch": (2.0 * fk / max(fn, 1) + wk / max(wn, 1)) * 1024.0}
+                    "hbm_bytes_per_launch": (2.0 * fk / max(fn, 1) + wk / max(wn, 1)) * 1024.0,
+                    "kernel_source_sha16": source_stamp(cls)}
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950 correction, "
                     "MI355X_MICROARCH.md HBM section), KB -> bytes; WRITE_SIZE uncalibrated; averages over all launches "
                     "of the class in the profiled bench run")
     dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json")
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"{k:28s} launches {v['launches']:6d}  HBM {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
 
 
