@@ -74,7 +74,7 @@ struct ModeScope {
 // Opt-in activation range check of the f16x3 mode (dpc_unet*_set_range_check).  Range contract per kernel family: every f16x3
 // kernel represents |x| <= 4094 with 22 significant bits; beyond it the direct convolutions / implicit GEMMs / stem (conv3f3.hip /
 // igemm6.hip / stem7x6.hip: pre-scale SA = 16) CLAMP at 65504 / 2^4 = 4094, while the Winograd convolution (conv3w.hip: no
-// pre-scale) stays exact up to 32752 (plain input) / 5676 (fused GroupNorm input) and then produces inf -> NaN.  With the check on, every f16x3 conv / implicit
+// pre-scale; since r03 2^3 inside the operand split) stays exact up to 4094 (plain input) / 5676 (fused GroupNorm input) and then produces inf -> NaN.  With the check on, every f16x3 conv / implicit
 // GEMM / stem launch of a forward is preceded by a streaming pass over its input (after the fused GroupNorm+SiLU where the
 // halo staging applies one) that records the first op whose input leaves the range; the forward then FAILS instead of
 // returning a result computed from clamped activations.  Off by default (costs one extra read of every conv input).

@@ -13,8 +13,9 @@
 //   * Loader waves 4-7: request the 6 halo frames of an (h, w, channel-quad) item one chunk ahead (raw buffer loads, hand-counted
 //     vmcnt), apply the producer's GroupNorm + (scale, shift) + SiLU, form V0..V3 of both pairs in fp32, split into the two fp16
 //     planes and write the 8 TRANSFORMED frames to the double-buffered swizzled halo (800 points x 64 B).  Operand pre-scale:
-//     none for a plain input, 4 log2(e) for the fused activation (it falls out of the SiLU evaluation); |V| <= 2 |d|, so the
-//     fp16 range ends at |x| = 32752 / 5676 (beyond it the operand is inf and the output NaN -- not clamped).
+//     2^3 for a plain input (folded into the split's v_fma_mix), 4 log2(e) for the fused activation (it falls out of the SiLU
+//     evaluation); |V| <= 2 |d|, so the fp16 range ends at |x| = 4094 / 5676 (beyond it the operand is inf and the output NaN -- not
+//     clamped; 4094 is the range every f16x3 kernel guarantees and the always-on sentinel watches, common.h).
 //   * MFMA waves 0-3: wave k owns Winograd component k of the whole tile (4 slabs of 32 points x 64 channels, transposed
 //     accumulators exactly as conv3f3c), streams ITS transformed weights U_k ([4][9 taps][chunk][n][2 planes][16] fp16 made by
 //     launch_pack_weights_w3) with the same running pointer / 3-deep register ring, 9 taps x 24 MFMAs per chunk.
@@ -37,7 +38,11 @@
 namespace dpc {
 
 namespace w3 {
-constexpr float SAW = 1.0f;                 // activation pre-scale of the un-normalised path (see the loader: hi = one v_cvt_pk)
+constexpr float SAW = 8.0f;                 // activation pre-scale of the un-normalised path, applied inside the operand split
+                                            // (v_fma_mix, the constant in an SGPR): 65504 / 8 / 2 (|V| <= 2 |d|) = 4094 is
+                                            // exactly the activation range every f16x3 kernel guarantees, and the remainder plane
+                                            // stays a NORMAL fp16 down to |x| = 2^-6 (r02's SAW = 1: 2^-3; inputs of magnitude 1e-3
+                                            // then lost 4 bits -- measured 1.3e-5 of the output range instead of < 3e-6)
 constexpr int TFO = 4;                      // output frames per tile
 constexpr int HFI = 6;                      // input halo frames
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w3[];
     unsigned char* halo = smem_w3;                      // two buffers at 0 and HBS
 
-    // operand pre-scales undone in the epilogue: activations SAW = 1 (plain input) or 4 log2(e) (fused GroupNorm + SiLU, see the loader)
+    // operand pre-scales undone in the epilogue: activations SAW = 2^3 (plain input) or 4 log2(e) (fused GroupNorm + SiLU, see the loader)
     const float descale = GN ? (float)(1.0 / (4.0 * 1.4426950408889634 * 4096.0)) : 1.0f / (SAW * SW);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -251,12 +256,24 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     uint2 p1, p2;
-                    p1.x = cvt_pk_f16(v[k].x, v[k].y);
-                    p1.y = cvt_pk_f16(v[k].z, v[k].w);
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(p2.x) : "v"(v[k].x), "v"(v[k].y), "v"(p1.x));
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(p1.y));
+                    if constexpr (GN) {       // the fused activation already carries its scale (4 log2 e): plain convert + remainder
+                        p1.x = cvt_pk_f16(v[k].x, v[k].y);
+                        p1.y = cvt_pk_f16(v[k].z, v[k].w);
+                        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(p2.x) : "v"(v[k].x), "v"(v[k].y), "v"(p1.x));
+                        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(p1.y));
+                    } else {                  // plain input: h1 = fp16(8 x), h2 = fp16(8 x - h1), the scale folded into v_fma_mix (SAW)
+                        const float sc = SAW;         // (8.0 is not an inline constant: one SGPR operand)
+                        asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                            : "=&v"(p1.x) : "v"(v[k].x), "v"(v[k].y), "s"(sc));
+                        asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                            : "=&v"(p1.y) : "v"(v[k].z), "v"(v[k].w), "s"(sc));
+                        asm("v_fma_mixlo_f16 %0, %1, %4, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %4, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(p2.x) : "v"(v[k].x), "v"(v[k].y), "v"(p1.x), "s"(sc));
+                        asm("v_fma_mixlo_f16 %0, %1, %4, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %4, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(p1.y), "s"(sc));
+                    }
                     *reinterpret_cast<uint2*>(q0 + (pr * 4 + k) * 6400) = p1;
                     *reinterpret_cast<uint2*>(q1 + (pr * 4 + k) * 6400) = p2;
                     if (GN && (k & 1)) __builtin_amdgcn_sched_barrier(0);     // (register budget of the fused-activation variant)

@@ -691,10 +691,24 @@ class HipDesignGradient:
         self.calls = 0
         self.last_calibration = None
 
+    # largest activation of the two nets: the level-0 tensors [B T H W, dim] fp32 (dim = image_size, inference_2d_jellyfish.py
+    # load_model).  The kernels address a tensor with 32-bit BYTE offsets inside buffer descriptors: keep every tensor below 2 GB.
+    _MAX_TENSOR_BYTES = 3 << 29                 # 1.6 GB (measured: 1.34 GB tensors run, 2.68 GB fault)
+
     def __call__(self, x, bd_0):
         check = self.calibrated and (self.calls == 0 or (self.check_every > 0 and self.calls % self.check_every == 0))
         self.calls += 1
-        return self._run(x, bd_0, check)
+        B, T, _, H, W = x.shape
+        per_traj = T * H * W * max(self.force.mid // 8, 64) * 4            # bytes of a level-0 activation per trajectory (dim = mid / 8)
+        chunk = max(1, self._MAX_TENSOR_BYTES // per_traj)
+        if B <= chunk:
+            return self._run(x, bd_0, check)
+        # J128 at 16 trajectories per GPU (128 x 128 x 20 frames, dim 128): the level-0 activations would be 2.7 GB -> the batch is
+        # processed in chunks of <= `chunk` trajectories (they are independent); the range calibration runs on the first chunk
+        outs = []
+        for b0 in range(0, B, chunk):
+            outs.append(self._run(x[b0:b0 + chunk].contiguous(), bd_0[b0:b0 + chunk].contiguous(), check and b0 == 0))
+        return torch.cat(outs, dim=0)
 
     def _run(self, x, bd_0, check):
         B, T, Cd, H, W = x.shape

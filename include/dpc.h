@@ -140,7 +140,7 @@ int dpc_unet3d_set_range_check(dpc_unet3d_t h, int enable);
  * dpc_unet3d_range_status reads that word (one host sync; reset != 0 clears it): DPC_OK, or DPC_ERR_STATE when any forward since
  * the last cleared status left the range.  The Python sampler calls it once at the end of sample().  Contract of the f16x3
  * mode, per kernel family: activations up to |x| <= 4094 are represented with 22 significant bits by EVERY kernel; beyond it the
- * direct convolutions / implicit GEMMs / stem clamp at 4094 and the Winograd convolution stays exact up to 32752 (plain input) /
+ * direct convolutions / implicit GEMMs / stem clamp at 4094 and the Winograd convolution stays exact up to 4094 (plain input, pre-scale 2^3) /
  * 5676 (fused GroupNorm input) and then yields inf -> NaN; weights must satisfy |w| <= 15.99 (checked by dpc_unet3d_finalize). */
 int dpc_unet3d_range_status(dpc_unet3d_t h, int reset, dpc_stream_t stream);
 int dpc_unet3d_debug_taps(dpc_unet3d_t h, int enable);
