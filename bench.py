@@ -485,6 +485,7 @@ def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
     for T in (4, 4, 20):
         a = J.build_parser().parse_args(["--synthetic", "True", "--batch_size", str(batch), "--num_batches", "1", "--timesteps", str(T),
                                          "--sampling_timesteps", str(T), "--image_size", str(image_size), "--frames", str(frames),
+                                         "--surrogate_dim", "64",      # the released surrogates' width (ForceUnet's head is Linear(512, .))
                                          "--inference_result_path", "/tmp/dpc_bench_j128"])
         a.device = ctx.device
         torch.manual_seed(0)

@@ -192,6 +192,10 @@ int launch_igemm(const IgemmParams& p, hipStream_t s);
 int igemm_mode_default();          // 0: native fp32 MFMA (env DPC_IGEMM_MODE=f32), 1: bf16x6 (default)
 size_t igemm6_packed_bytes(int Npad, int K, int ntaps);
 int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s);
+// 256 x 128 tile with both operands staged through LDS (igemm_wide.hip): long reductions into >= 128 columns; p as prepared by
+// launch_igemm6 (nsl > 1: split-K slices, raw partials into p.part)
+bool igemm3w_supported(const IgemmParams& p);
+int launch_igemm3w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s);
 int launch_pack_weights_g6(const float* w, void* wp6, int N, int Npad, int K, int ntaps, long long stride_n,
                            long long stride_c, const int* tap_off_host, hipStream_t s);
 // generic weight re-pack: wp[tap][kc][n][kk] = w[n*stride_n + (kc*32+kk)*stride_c + tap_off[tap]]

@@ -611,8 +611,12 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
             IgemmParams q = p;
             q.ksplit = nsl;
             q.part = scratch;
-            hipLaunchKernelGGL((igemm3_kernel<64, false>), dim3((unsigned)nwg, nsl), dim3(256), lds3, s, q, (const unsigned char*)wp6);
-            DPC_LAUNCH_CHECK();
+            if (igemm3w_supported(q)) {
+                if (int rc = launch_igemm3w(q, wp6, nsl, s)) return rc;
+            } else {
+                hipLaunchKernelGGL((igemm3_kernel<64, false>), dim3((unsigned)nwg, nsl), dim3(256), lds3, s, q, (const unsigned char*)wp6);
+                DPC_LAUNCH_CHECK();
+            }
             const long long MN = p.M * p.N;
             hipLaunchKernelGGL(igemm3_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, scratch, p.bias, p.resid,
                                p.out, MN, p.N, nsl, p.descale, p.oflag);
@@ -620,6 +624,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
             return DPC_OK;
         }
         const bool vec = (p.N & 3) == 0 && p.out_mode != 1;
+        if (igemm3w_supported(p)) return launch_igemm3w(p, wp6, 1, s);
         if (wide) {
             if (vec) hipLaunchKernelGGL((igemm3_kernel<128, true>), dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);
             else hipLaunchKernelGGL((igemm3_kernel<128, false>), dim3(mtiles * (p.Npad / 128)), dim3(256), lds3, s, p, (const unsigned char*)wp6);

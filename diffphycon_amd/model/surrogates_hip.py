@@ -467,6 +467,11 @@ class HipForceUnet:
         self.mid2 = _Res(self.ctx, sd, "mid_block2.", mid, 0, mid, False)
         self.Wf, self.bf = _f(sd["final.weight"]), _f(sd["final.bias"])
         self.mid = mid
+        if self.Wf.shape[1] != mid:
+            # the reference hard-codes `self.final = nn.Linear(512, out_dim)` (diffusion_2d_jellyfish.py:454) and fails at
+            # `self.final(x)` for any width whose bottleneck is not 512 channels (dim != 64): same error, up front
+            raise ValueError(f"ForceUnet: final Linear expects {self.Wf.shape[1]} features but the bottleneck has {mid} channels "
+                             f"(dim = {dim}, dim_mults x8): the reference's ForceUnet only works for dim = 64")
 
     def forward_cl(self, x, n):
         """x: channels-last [n * H * W, 4].  Returns force [n, out_dim]."""

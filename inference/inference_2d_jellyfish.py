@@ -53,8 +53,12 @@ def load_model(args):
     diffusion_joint = _ddpm(model_joint, args, eval_2ddpm=False)
     model_thetas = Unet3D_with_Conv3D(dim=64, out_dim=1, dim_mults=(1, 2, 4), channels=inp_dim).to(args.device)
     diffusion_thetas = _ddpm(model_thetas, args, eval_2ddpm=False)
-    force_model = ForceUnet(dim=args.image_size, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4)
-    bd_updater = Unet(dim=args.image_size, out_dim=3, dim_mults=(1, 2, 4, 8), channels=3)
+    # the reference builds both surrogates with dim = args.image_size (inference_2d_jellyfish.py:257-272) but ForceUnet's head is a
+    # hard-coded Linear(512, .) (diffusion_2d_jellyfish.py:454): only dim = 64 runs.  --surrogate_dim (host-side extra) keeps the
+    # released 64-wide surrogates at other resolutions (BASELINE.json's J128: 128 x 128 images); default = the reference's expression
+    sdim = args.surrogate_dim or args.image_size
+    force_model = ForceUnet(dim=sdim, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4)
+    bd_updater = Unet(dim=sdim, out_dim=3, dim_mults=(1, 2, 4, 8), channels=3)
     if not args.synthetic:
         Trainer(diffusion_joint, results_path=args.diffusion_joint_model_path).load(args.diffusion_joint_checkpoint)
         Trainer(diffusion_thetas, results_path=args.diffusion_w_model_path).load(args.diffusion_w_checkpoint)
@@ -198,6 +202,7 @@ def build_parser():
     # extra (not in the reference)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--synthetic", default=False, type=eval)
+    p.add_argument("--surrogate_dim", default=None, type=int, help="width of the two 2-D surrogates (default: image_size, as the reference)")
     p.add_argument("--timesteps", default=1000, type=int, help="debug: shorter diffusion chain")
     p.add_argument("--is_testdata", default=True, type=bool, help="50-simulation test split (reference default)")
     return p

@@ -304,3 +304,15 @@ def test_design_gradient_full_width_nets_vs_autograd(dev):
     with torch.no_grad():
         ref = bd(bd0e.reshape(-1, 3, 32, 32), th)
     assert rel(design.unet(bd0e.reshape(-1, 3, 32, 32), th), ref) < 2e-5
+
+
+def test_force_unet_head_width_mismatch_is_an_error_not_a_fault(dev):
+    """The reference's ForceUnet ends in a hard-coded nn.Linear(512, out_dim) (diffusion_2d_jellyfish.py:454): with dim != 64 --
+    e.g. `dim = args.image_size` at 128 x 128 (inference_2d_jellyfish.py:257-262) -- the reference raises a shape error at
+    `self.final(x)`.  The HIP path reports the same mismatch at construction (r03: it used to read past the weight)."""
+    from diffphycon_amd.model import surrogates_2d as S2
+    from diffphycon_amd.model import surrogates_hip as SH
+    fm = S2.ForceUnet(dim=128, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4).to(dev).eval()
+    with pytest.raises(ValueError, match="only works for dim = 64"):
+        SH.HipForceUnet(fm, 128)
+    SH.HipForceUnet(S2.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4).to(dev).eval(), 128)     # dim 64 at 128 x 128: fine

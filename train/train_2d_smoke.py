@@ -55,7 +55,7 @@ def main(argv=None):
     FLAGS = build_parser().parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))      # (several gloo ranks may share one GPU in the tests)
     torch.cuda.set_device(device)
     if world > 1:
         parallel.init_process_group(rank, world, device)
