@@ -195,6 +195,7 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s);
 // 256 x 128 tile with both operands staged through LDS (igemm_wide.hip): long reductions into >= 128 columns; p as prepared by
 // launch_igemm6 (nsl > 1: split-K slices, raw partials into p.part)
 bool igemm3w_supported(const IgemmParams& p);
+int igemm3w_slices(const IgemmParams& p);      // split-K slices by shape (N, reduction length), never by the batch
 int launch_igemm3w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s);
 int launch_pack_weights_g6(const float* w, void* wp6, int N, int Npad, int K, int ntaps, long long stride_n,
                            long long stride_c, const int* tap_off_host, hipStream_t s);

@@ -1,13 +1,21 @@
 // LDS-tiled 256 x 128 form of the f16x3 implicit GEMM (igemm6.hip: igemm3_kernel) for the GEMM-shaped deep levels of the Burgers
 // U-Net (model/burgers_1d/unet.py:387-431: 3x3 convolutions at 4x32 / 2x16 / 1x8 images, M = 2-32 k rows, K = 9 C = 2304-18432, N =
-// 256-1024) and every other launch with a long reduction and N >= 128.  igemm3's 128 x 64 / 128 x 128 tiles stream each wave's
-// weight fragments from L2 (22 FLOP per byte moved into the CU): those levels ran L2-bandwidth bound at ~150 TF/s.  Here a
-// 512-thread workgroup (8 waves as 4 x 2, 64 x 64 accumulators each) stages BOTH operands of a 32-channel chunk through LDS --
-// activations converted and split on the way in, as igemm3 does; the pre-split weights of the 128-column tile copied in MFMA
-// fragment order ([k-step][plane][n][half][16 B]: conflict-free b128 reads) -- so a byte fetched into the CU feeds 44 FLOP.
-// Both LDS images are double-buffered (one barrier per chunk); the B fragments of the two k-steps of a chunk live in SEPARATE
-// registers (no ds_read ever targets a register an in-flight MFMA still reads: DESIGN.md 6.2).  Same arithmetic, operand scales,
-// partial-product order, split-K protocol and epilogues as igemm3_kernel; the reduction is walked in the same (tap, chunk) order.
+// 256-1024) and every other launch with a long reduction and N >= 128.  igemm3's 128 x 64 tiles stream each wave's weight
+// fragments from L2 (22 FLOP per byte moved into the CU): those levels ran at ~150 TF/s.  Here a 512-thread workgroup (8 waves as
+// 4 x 2, 64 x 64 accumulators each) stages BOTH operands of a 32-channel chunk through LDS -- activations converted and split on
+// the way in, as igemm3 does; the pre-split weights of the 128-column tile copied in MFMA fragment order ([k-step][plane][32-column
+// block][half][n][16 B]: conflict-free b128 reads AND writes) -- so a byte fetched into the CU feeds 44 FLOP.
+//
+// Pipeline (r03, second form): the loads of chunk i+2 are issued while chunk i is multiplied, held in registers for a whole
+// iteration and written to the other LDS image after chunk i+1's barrier -- two register stages with static names (the loop is
+// unrolled by two), one barrier per chunk.  The first form prefetched one chunk ahead through lambdas with `if (more)` around the
+// loads: hipcc kept the weight stage in SCRATCH (load -> s_waitcnt -> scratch_store inside the loop), branched around every
+// activation load and fetched the tap offsets with global_load_ubyte + vmcnt(0) -- every iteration paid a full memory latency
+// (3 us per chunk, 26 % of the MFMA-bound rate).  Now: no branch in the loop body (out-of-image rows load row 0 and are zeroed
+// at the split; iterations past the end re-load the last chunk), the per-row (frame, y, x) decomposition is done once, and the
+// tap offsets come from an LDS table (lgkmcnt, not vmcnt).
+// Same arithmetic, operand scales, partial-product order, split-K protocol and epilogues as igemm3_kernel; the reduction is walked
+// in the same (tap, chunk) order, so the sums are bit-identical to the narrow kernel's.
 #include <algorithm>
 
 #include "common.h"
@@ -20,17 +28,29 @@ constexpr int BM = 256, BN = 128, BK = 32;
 constexpr int RS = 144;                     // LDS bytes per A row (2 planes x 64 B + 16 pad), as igemm3
 constexpr int WROW = 128;                   // packed weight bytes per output channel per iteration
 constexpr int ABYTES = BM * RS, BBYTES = BN * WROW;
-constexpr int LDS = 2 * (ABYTES + BBYTES);
+constexpr int TAPOFF = 2 * (ABYTES + BBYTES);
+constexpr int LDS = TAPOFF + 32 * 4;
 }  // namespace gw
 
 typedef _Float16 f16x8_w __attribute__((ext_vector_type(8)));
 
-template <bool VEC>
+struct WStage {             // one chunk in flight: 2 activation rows x 8 channels, 2 x 16 weight bytes, row validity bits
+    f32x4 a[4];             // [row i][half]: a[2 i], a[2 i + 1]
+    uint4 b[2];
+    unsigned ok;
+};
+
+// LDS images (r03 PMC: half of the LDS-array cycles of the first form were bank conflicts):
+//   A  [row 256][144 B]: plane 0 at +0, plane 1 at +64; a fragment read (lane = row, 16 B) walks 9 slots per row -> the 16-lane
+//      groups of ds_read_b128 hit 16 different slots; a thread writes 8 channels = 16 B per plane, and the 8 lanes of a
+//      ds_write_b128 group hold 8 CONSECUTIVE ROWS of one column piece (slots 9 r + j: distinct mod 8).
+//   B  [k-step 2][plane 2][32-column block 4][half 2][n 32][16 B]: a fragment read covers 1 KB contiguously; the copy-in gives the
+//      8 lanes of a write group 8 consecutive columns of one 16-byte piece, while one load instruction still covers 8 whole
+//      128-byte weight rows (lane = piece * 8 + column).
+template <bool SPLIT, int V>
 __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace gw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-    auto Abuf = [&](int i) { return smem_w + i * ABYTES; };
-    auto Bbuf = [&](int i) { return smem_w + 2 * ABYTES + i * BBYTES; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
     const int ntn = p.Npad / BN;
@@ -42,71 +62,96 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
     }
     const long long m0 = (long long)__builtin_amdgcn_readfirstlane(bid / ntn) * BM;
     const int n0 = __builtin_amdgcn_readfirstlane((bid % ntn) * BN);
-    // ---- A: thread -> 4 rows (tid / 8 + 64 i), one float4 column (tid % 8) * 4
-    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    int* taptab = reinterpret_cast<int*>(smem_w + TAPOFF);
+    if (tid < 32) taptab[tid] = (p.tdf[tid] & 0xff) | ((p.tdh[tid] & 0xff) << 8) | ((p.tdw[tid] & 0xff) << 16);
+
+    // ---- A: thread -> rows wave * 32 + i * 16 + (lane / 32) * 8 + lane % 8 (i = 0, 1), channels ((lane / 8) % 4) * 8 .. + 7 of the
+    //      chunk; the row geometry is fixed for the whole launch
+    const int acol = ((lane >> 3) & 3) * 8;
+    const int arow0 = wave * 32 + (lane >> 5) * 8 + (lane & 7);
     const int HoWo = p.Ho * p.Wo;
     const int K = p.C0 + p.C1;
-    f32x4 ra[4];
-    long long roff[4];
-    bool rvalid[4];
-    int cur_tap = -1;
-    auto load_a = [&](int it) {
-        const int tap = it / p.kchunks, kc = it - tap * p.kchunks;
-        if (tap != cur_tap) {
-            cur_tap = tap;
-            const int df = p.tdf[tap], dh = p.tdh[tap], dw = p.tdw[tap];
+    int rf[2], rh[2], rw[2];
+    long long rbase[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long long m = m0 + arow + 64 * i;
-                const bool ok = m < p.M;
-                const long long mm = ok ? m : 0;
-                const int bf = (int)(mm / HoWo);
-                const int hw = (int)(mm - (long long)bf * HoWo);
-                const int ho = hw / p.Wo;
-                const int fi = bf % p.F + df, hi = ho * p.sh + dh, wi = (hw - ho * p.Wo) * p.sw + dw;
-                rvalid[i] = ok && (unsigned)fi < (unsigned)p.F && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
-                roff[i] = ((long long)(bf + df) * p.Hi + hi) * p.Wi + wi;
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + arow0 + 16 * i;
+        const bool ok = m < p.M;
+        const long long mm = ok ? m : 0;
+        const int bf = (int)(mm / HoWo);
+        const int hw = (int)(mm - (long long)bf * HoWo);
+        const int ho = hw / p.Wo;
+        rf[i] = ok ? bf % p.F : -(1 << 20);                       // (a row past M fails every range test below)
+        rh[i] = ho * p.sh;
+        rw[i] = (hw - ho * p.Wo) * p.sw;
+        rbase[i] = ((long long)bf * p.Hi + rh[i]) * p.Wi + rw[i];
+    }
+    const float* pa0[2] = {p.a0, p.a0};                          // this tap's pixel in source 0 / source 1 (row 0 when out of the image)
+    const float* pa1[2] = {p.a1, p.a1};
+    unsigned rok = 0;
+    // weights: load k (0, 1) of a thread = column wave * 16 + k * 8 + lane % 8, 16-byte piece lane / 8 = plane * 4 + k-step * 2 + half
+    const int piece = lane >> 3;
+    const int bcol = wave * 16 + (lane & 7);
+    const unsigned char* wsrc = wp6 + ((long long)n0 + bcol) * WROW + piece * 16;
+    const int bdst = ((((piece >> 1) & 1) * 2 + (piece >> 2)) * 4 + (bcol >> 5)) * 1024 + (piece & 1) * 512 + (bcol & 31) * 16;
+    const long long wstep = (long long)p.Npad * WROW;
+    const int nit_all = p.ntaps * p.kchunks;
+    const int nsl = SPLIT ? p.ksplit : 1;
+    const int it0 = (int)((long long)nit_all * blockIdx.y / nsl), niter = (int)((long long)nit_all * (blockIdx.y + 1) / nsl);
+    __syncthreads();                                              // tap table visible
+
+    int cur_tap = -1;
+    auto issue = [&](int it_req, WStage& st) {
+        const int it = it_req < niter ? it_req : niter - 1;       // past the end: re-load the last chunk (never multiplied)
+        const int tap = it / p.kchunks, kc = it - tap * p.kchunks;
+        if (tap != cur_tap) {                                     // wave-uniform, once per tap
+            cur_tap = tap;
+            const int t = taptab[tap];
+            const int df = (signed char)(t & 0xff), dh = (signed char)((t >> 8) & 0xff), dw = (signed char)((t >> 16) & 0xff);
+            const long long d = ((long long)df * p.Hi + dh) * p.Wi + dw;
+            rok = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool v = (unsigned)(rf[i] + df) < (unsigned)p.F && (unsigned)(rh[i] + dh) < (unsigned)p.Hi &&
+                               (unsigned)(rw[i] + dw) < (unsigned)p.Wi;
+                const long long px = v ? rbase[i] + d : 0;
+                pa0[i] = p.a0 + px * p.C0;
+                pa1[i] = p.a1 + px * p.C1;
+                rok |= v ? 1u << i : 0u;
             }
         }
         const int c = kc * BK + acol;
-        const float* src;
-        int cs, cc;
-        if (c < p.C0) { src = p.a0; cs = p.cs0; cc = c; }
-        else { src = p.a1; cs = p.C1; cc = c - p.C0; }
-        const bool cok = c < K;
+        const bool cok = c < K;                                   // a chunk column past K (K % 32 != 0) reads channel 0 and is zeroed
+        const bool s0 = c < p.C0 || !cok;
+        const int cc = cok ? (s0 ? c : c - p.C0) : 0;
+        st.ok = cok ? rok : 0u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && rvalid[i]) v = *reinterpret_cast<const f32x4*>(src + roff[i] * cs + cc);
-            ra[i] = v;
+        for (int i = 0; i < 2; ++i) {
+            const float* q = (s0 ? pa0[i] : pa1[i]) + cc;
+            st.a[2 * i] = *reinterpret_cast<const f32x4*>(q);
+            st.a[2 * i + 1] = *reinterpret_cast<const f32x4*>(q + 4);
         }
+        const unsigned char* ws = wsrc + (long long)it * wstep;
+        st.b[0] = *reinterpret_cast<const uint4*>(ws);
+        st.b[1] = *reinterpret_cast<const uint4*>(ws + 8 * WROW);
     };
-    auto store_a = [&](unsigned char* A) {
+    auto stash = [&](const WStage& st, int buf) {
+        unsigned char* A = smem_w + buf * ABYTES;
+        unsigned char* B = smem_w + 2 * ABYTES + buf * BBYTES;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = ra[i] * p.act_scale;
-            uint2 p1, p2;
-            const float x0 = h3::sat16(v.x), x1 = h3::sat16(v.y), x2 = h3::sat16(v.z), x3 = h3::sat16(v.w);
-            p1.x = h3::cvt_pk(x0, x1); p1.y = h3::cvt_pk(x2, x3);
-            p2.x = f16_sub_pk(x0, x1, p1.x); p2.y = f16_sub_pk(x2, x3, p1.y);
-            unsigned char* dst = A + (arow + 64 * i) * RS + acol * 2;
-            *reinterpret_cast<uint2*>(dst) = p1;
-            *reinterpret_cast<uint2*>(dst + 64) = p2;
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = st.ok >> i & 1;
+            const f32x4 u = ok ? st.a[2 * i] * p.act_scale : z, v = ok ? st.a[2 * i + 1] * p.act_scale : z;
+            h3::f16x8 pl[2];
+            h3::split8(h3::sat16(u.x), h3::sat16(u.y), h3::sat16(u.z), h3::sat16(u.w), h3::sat16(v.x), h3::sat16(v.y), h3::sat16(v.z),
+                       h3::sat16(v.w), pl);
+            unsigned char* dst = A + (arow0 + 16 * i) * RS + acol * 2;
+            *reinterpret_cast<h3::f16x8*>(dst) = pl[0];
+            *reinterpret_cast<h3::f16x8*>(dst + 64) = pl[1];
         }
-    };
-    // ---- B: thread -> column n = tid / 4, 32-byte part (tid % 4) = plane * 2 + k-step of its 128-byte row
-    const int bn = tid >> 2, bpart = tid & 3;
-    uint4 rb[2];
-    auto load_b = [&](int it) {
-        const unsigned char* src = wp6 + ((long long)it * p.Npad + n0 + bn) * WROW + bpart * 32;
-        rb[0] = *reinterpret_cast<const uint4*>(src);
-        rb[1] = *reinterpret_cast<const uint4*>(src + 16);
-    };
-    auto store_b = [&](unsigned char* B) {
-        const int pl = bpart >> 1, ks = bpart & 1;
-        unsigned char* dst = B + ((ks * 2 + pl) * BN + bn) * 32;
-        *reinterpret_cast<uint4*>(dst) = rb[0];
-        *reinterpret_cast<uint4*>(dst + 16) = rb[1];
+        *reinterpret_cast<uint4*>(B + bdst) = st.b[0];
+        *reinterpret_cast<uint4*>(B + bdst + 8 * 16) = st.b[1];
     };
 
     f32x16 acc[2][2];
@@ -117,53 +162,66 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     const int a_lane = (wm * 64 + l31) * RS + hh * 16;
-    const int b_lane = (wn * 64 + l31) * 32 + hh * 16;
-    const int nit_all = p.ntaps * p.kchunks;
-    const int nsl = (!VEC && p.ksplit > 1) ? p.ksplit : 1;
-    const int it0 = (int)((long long)nit_all * blockIdx.y / nsl), niter = (int)((long long)nit_all * (blockIdx.y + 1) / nsl);
-    load_a(it0);
-    load_b(it0);
-    store_a(Abuf(0));
-    store_b(Bbuf(0));
-    __syncthreads();
-    for (int it = it0; it < niter; ++it) {
-        const bool more = it + 1 < niter;
-        if (more) { load_a(it + 1); load_b(it + 1); }
-        const unsigned char* A = Abuf((it - it0) & 1);
-        const unsigned char* B = Bbuf((it - it0) & 1);
-        f16x8_w b[2][2][2];                  // [k-step][nt][plane]: both k-steps' fragments in separate registers
+    const int b_lane = wn * 2048 + hh * 512 + l31 * 16;
+    // The matrix work trails the fragment reads by half a chunk: right after a barrier a wave issues the k-step-0 reads of the new
+    // image and multiplies the k-step-1 fragments it read BEFORE the barrier (held in registers), so the LDS latency that follows
+    // every barrier -- both waves of a SIMD leave it together -- is covered by 12 MFMAs instead of idling the matrix pipe.
+    f16x8_w fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];      // [mt | nt][plane] of k-step 0 / 1
+    auto read_frags = [&](int buf, int ks, f16x8_w (&fa)[2][2], f16x8_w (&fb)[2][2]) {
+        const unsigned char* A = smem_w + buf * ABYTES;
+        const unsigned char* B = smem_w + 2 * ABYTES + buf * BBYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int pl = 0; pl < 2; ++pl) fb[nt][pl] = *reinterpret_cast<const f16x8_w*>(B + ((ks * 2 + pl) * 4 + nt) * 1024 + b_lane);
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    b[ks][nt][pl] = *reinterpret_cast<const f16x8_w*>(B + ((ks * 2 + pl) * BN + nt * 32) * 32 + b_lane);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8_w a[2][2];
+            for (int pl = 0; pl < 2; ++pl) fa[mt][pl] = *reinterpret_cast<const f16x8_w*>(A + a_lane + mt * 32 * RS + pl * 64 + ks * 32);
+    };
+    auto mfma12 = [&](const f16x8_w (&fa)[2][2], const f16x8_w (&fb)[2][2]) {
+        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};         // small terms first (as igemm3)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    a[mt][pl] = *reinterpret_cast<const f16x8_w*>(A + a_lane + mt * 32 * RS + pl * 64 + ks * 32);
-            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};     // small terms first (as igemm3)
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], b[ks][nt][PB[term]], acc[mt][nt], 0, 0, 0);
-        }
-        if (more) {
-            store_a(Abuf(((it - it0) & 1) ^ 1));
-            store_b(Bbuf(((it - it0) & 1) ^ 1));
-        }
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][PA[term]], fb[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+    };
+
+    // One phase = one chunk (image `img`), one barrier:  read k-step 0 | multiply the previous chunk's k-step 1 (its fragments were
+    // read before the barrier) and convert + store the NEXT chunk into the other image | multiply k-step 0 | read k-step 1 | issue
+    // the loads of the chunk after next into the stage just stored.  A fragment register is re-loaded only after the MFMAs that
+    // read it and twelve more have been issued (the matrix pipe reads its B operand while executing; an LDS return must never
+    // overtake a queued MFMA -- DESIGN.md 6.2): the scheduling barriers pin exactly that order and leave the rest to hipcc.
+    WStage s0, s1;
+    auto phase = [&](int img, WStage& st, int it_next, bool trail) {
+        read_frags(img, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (trail) mfma12(fa1, fb1);
+        stash(st, img ^ 1);
+        mfma12(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(img, 1, fa1, fb1);
+        issue(it_next, st);
         __syncthreads();
+    };
+    issue(it0, s0);
+    issue(it0 + 1, s1);
+    stash(s0, 0);
+    issue(it0 + 2, s0);
+    __syncthreads();
+    phase(0, s1, it0 + 3, false);
+    int it = it0 + 1;
+    for (; it + 1 < niter; it += 2) {    // chunk `it` in image 1 (loads in s0 -> image 0 = chunk it+1), then chunk it+1 in image 0
+        phase(1, s0, it + 3, true);
+        phase(0, s1, it + 4, true);
     }
+    if (it < niter) phase(1, s0, it + 3, true);
+    mfma12(fa1, fb1);                    // k-step 1 of the last chunk
     // ---- epilogue
-    if (!VEC && p.ksplit > 1) {        // raw partial accumulators [slice][M][N]; finished by igemm3_reduce_kernel
+    if constexpr (SPLIT) {             // raw partial accumulators [slice][M][N]; finished by igemm3_reduce_kernel
         float* pb = p.part + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -177,9 +235,7 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
                     if (n < p.N) pb[m * p.N + n] = acc[mt][nt][r];
                 }
             }
-        return;
-    }
-    if constexpr (VEC) {
+    } else {
         const int q3 = l31 & 3;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -197,9 +253,9 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
 #define DPC_QUAD_XCHG(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
                         const float r0 = DPC_QUAD_XCHG(b0 ? x[0] : x[1], 0xB1), r1 = DPC_QUAD_XCHG(b0 ? x[2] : x[3], 0xB1);
                         const float y0 = b0 ? r0 : x[0], y1 = b0 ? x[1] : r0, y2 = b0 ? r1 : x[2], y3 = b0 ? x[3] : r1;
-                        const float s0 = DPC_QUAD_XCHG(b1 ? y0 : y2, 0x4E), s1 = DPC_QUAD_XCHG(b1 ? y1 : y3, 0x4E);
+                        const float s0_ = DPC_QUAD_XCHG(b1 ? y0 : y2, 0x4E), s1_ = DPC_QUAD_XCHG(b1 ? y1 : y3, 0x4E);
 #undef DPC_QUAD_XCHG
-                        x[0] = b1 ? s0 : y0; x[2] = b1 ? y2 : s0; x[1] = b1 ? s1 : y1; x[3] = b1 ? y3 : s1;
+                        x[0] = b1 ? s0_ : y0; x[2] = b1 ? y2 : s0_; x[1] = b1 ? s1_ : y1; x[3] = b1 ? y3 : s1_;
                     }
                     const int n = n0 + wn * 64 + nt * 32 + (l31 & ~3);
                     if (m >= p.M || n >= p.N) continue;
@@ -213,27 +269,48 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
     }
 }
 
-// shape-only rule (never the batch): long reductions into >= 128 columns, plain [M][N] output
+// shape-only rules (never the batch): long reductions into >= 128 columns, plain [M][N] output
 bool igemm3w_supported(const IgemmParams& p) {
     static const int on = debug_switch("DPC_IGEMM_LDSB", 1);
     const int nit = p.ntaps * p.kchunks;
-    return on && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && !p.a0_stride && p.N % 4 == 0 && p.Npad % 128 == 0 && p.N >= 128 && nit >= 64;
+    return on && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && !p.a0_stride && p.N % 4 == 0 && p.Npad % 128 == 0 && p.N >= 128 && nit >= 24;
+}
+// split-K slices of the wide kernel: the deep levels have few rows and many columns (N = 512: 2, N >= 1024: 4), >= 12 chunks each
+int igemm3w_slices(const IgemmParams& p) {
+    const int nit = p.ntaps * p.kchunks;
+    int nsl = p.N >= 1024 ? 4 : p.N >= 512 ? 2 : 1;
+    while (nsl > 1 && nit / nsl < 12) nsl >>= 1;
+    return nsl;
+}
+
+template <int V>
+static int launch_w(const IgemmParams& p, const void* wp6, int nsl, unsigned nwg, hipStream_t s) {
+    using namespace gw;
+    static DeviceOnce once;
+    if (!once) {
+        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<true, V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        once = true;
+    }
+    if (nsl > 1) hipLaunchKernelGGL((igemm3w_kernel<true, V>), dim3(nwg, nsl), dim3(512), LDS, s, p, (const unsigned char*)wp6);
+    else hipLaunchKernelGGL((igemm3w_kernel<false, V>), dim3(nwg), dim3(512), LDS, s, p, (const unsigned char*)wp6);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
 }
 
 int launch_igemm3w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s) {
     using namespace gw;
     const int mtiles = (int)((p.M + BM - 1) / BM);
     const unsigned nwg = (unsigned)mtiles * (p.Npad / BN);
-    static DeviceOnce once;
-    if (!once) {
-        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        once = true;
+    static const int v = debug_switch("DPC_IGEMM_WV", 0);
+    switch (v) {
+        case 1: return launch_w<1>(p, wp6, nsl, nwg, s);
+        case 2: return launch_w<2>(p, wp6, nsl, nwg, s);
+        case 3: return launch_w<3>(p, wp6, nsl, nwg, s);
+        case 4: return launch_w<4>(p, wp6, nsl, nwg, s);
+        case 5: return launch_w<5>(p, wp6, nsl, nwg, s);
+        default: return launch_w<0>(p, wp6, nsl, nwg, s);
     }
-    if (nsl > 1) hipLaunchKernelGGL(igemm3w_kernel<false>, dim3(nwg, nsl), dim3(512), LDS, s, p, (const unsigned char*)wp6);
-    else hipLaunchKernelGGL(igemm3w_kernel<true>, dim3(nwg), dim3(512), LDS, s, p, (const unsigned char*)wp6);
-    DPC_LAUNCH_CHECK();
-    return DPC_OK;
 }
 
 }  // namespace dpc
