@@ -194,6 +194,9 @@ size_t igemm6_packed_bytes(int Npad, int K, int ntaps);
 int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s);
 // 256 x 128 tile with both operands staged through LDS (igemm_wide.hip): long reductions into >= 128 columns; p as prepared by
 // launch_igemm6 (nsl > 1: split-K slices, raw partials into p.part)
+// 64-row x all-N panels for 1-tap ops with K <= 256 (igemm_panel.hip); p as prepared by launch_igemm6
+bool igemm3p_supported(const IgemmParams& p);
+int launch_igemm3p(const IgemmParams& p, const void* wp6, hipStream_t s);
 bool igemm3w_supported(const IgemmParams& p);
 int igemm3w_slices(const IgemmParams& p);      // split-K slices by shape (N, reduction length), never by the batch
 int launch_igemm3w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s);

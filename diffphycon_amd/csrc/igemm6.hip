@@ -15,8 +15,10 @@
 // 22-bit operands pre-scaled by 2^4 / 2^12, three partial products per product, A rows of 2 planes x 32 k fp16 = 128 B
 // + 16 B pad (144 B = 9 x 16 B), weights [iteration][n][2 planes][32 k] fp16, epilogue rescale by 2^-16.
 #include <algorithm>
+#include <cstdio>
 
 #include "common.h"
+#include "igemm_epilogue.h"
 
 namespace dpc {
 
@@ -331,8 +333,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
             *reinterpret_cast<uint2*>(dst + 64) = p2;
         }
     };
-    // weight fragments: [it][Npad][2][32] fp16 = 128 B per n; lane (n = l31, half hh) reads 8 k = 16 B per plane and k16 step
-    const unsigned char* wlane = wp6 + ((long long)n0 + wn * (BN / 2) + l31) * WROW + hh * 16;
+    // weight fragments: [it][Npad / 32][k-step][plane][half][n 32][16 B] (pack_weights_g6_kernel): lane (n = l31, half hh)
+    const unsigned char* wlane = wp6 + (long long)((n0 + wn * (BN / 2)) >> 5) * 4096 + hh * 512 + l31 * 16;
     f16x8_g wc[2][NT][2], wx[2][NT][2];
     auto ldw = [&](int it, f16x8_g (&w)[2][NT][2]) {
         const unsigned char* src = wlane + (long long)it * p.Npad * WROW;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    w[ks][nt][pl] = *reinterpret_cast<const f16x8_g*>(src + nt * 32 * WROW + pl * 64 + ks * 32);
+                    w[ks][nt][pl] = *reinterpret_cast<const f16x8_g*>(src + nt * 4096 + (ks * 2 + pl) * 1024);
     };
 
     f32x16 acc[2][NT];
@@ -421,50 +423,17 @@ __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmPa
     if constexpr (VEC) {
         const int q3 = l31 & 3;
         const long long bsmp = p.gn_raw ? m0 / p.gn_rows : 0;       // fused GroupNorm-apply residual: the tile lies inside one sample
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const long long m = m0 + wm * 64 + mt * 32 + 8 * g + 4 * hh + q3;      // this lane's row after the transpose
-                long long orow;
-                if (p.out_mode == 0) {
-                    orow = m * p.N;
-                } else {
-                    const long long mm = m < p.M ? m : 0;
-                    const long long bf = mm / HoWo;
-                    const int hw = (int)(mm - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
-                    orow = ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N;
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    float x[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = acc[mt][nt][4 * g + e];
-                    {   // 4 x 4 transpose across the lane quad: x[j] of lane L  <-  x[L] of lane j
-                        const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-#define DPC_QUAD_XCHG(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
-                        const float r0 = DPC_QUAD_XCHG(b0 ? x[0] : x[1], 0xB1), r1 = DPC_QUAD_XCHG(b0 ? x[2] : x[3], 0xB1);   // quad_perm [1,0,3,2]
-                        const float y0 = b0 ? r0 : x[0], y1 = b0 ? x[1] : r0, y2 = b0 ? r1 : x[2], y3 = b0 ? x[3] : r1;
-                        const float s0 = DPC_QUAD_XCHG(b1 ? y0 : y2, 0x4E), s1 = DPC_QUAD_XCHG(b1 ? y1 : y3, 0x4E);           // quad_perm [2,3,0,1]
-#undef DPC_QUAD_XCHG
-                        x[0] = b1 ? s0 : y0; x[2] = b1 ? y2 : s0; x[1] = b1 ? s1 : y1; x[3] = b1 ? y3 : s1;
-                    }
-                    const int n = n0 + wn * (BN / 2) + nt * 32 + (l31 & ~3);
-                    if (m >= p.M || n >= p.N) continue;
-                    f32x4 v = f32x4{x[0], x[1], x[2], x[3]} * p.descale;
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.N + n);
-                    if (p.gn_raw) {
-                        const f32x4* cf = reinterpret_cast<const f32x4*>(p.gn_coef) + (bsmp * (p.N >> 2) + (n >> 2)) * 5;
-                        f32x4 y = (*reinterpret_cast<const f32x4*>(p.gn_raw + m * p.N + n) - cf[0]) * cf[1] + cf[2];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + expf(-y[e]));
-                        v += y;
-                    }
-                    overflow_note4(p.oflag, v);          // f16x3 activation-range sentinel (common.h): this output may be split next
-                    *reinterpret_cast<f32x4*>(p.out + orow + n) = v;
-                }
-            }
+        auto mrow = [&](int mt, int g) { return m0 + wm * 64 + mt * 32 + 8 * g + 4 * hh + q3; };      // this lane's row after the transpose
+        auto orow = [&](int mt, int g) -> long long {
+            const long long m = mrow(mt, g);
+            if (p.out_mode == 0) return m * p.N;
+            const long long mm = m < p.M ? m : 0;
+            const long long bf = mm / HoWo;
+            const int hw = (int)(mm - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
+            return ((bf * (2 * (HoWo / p.Wo)) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N;
+        };
+        auto ncol = [&](int nt) { return n0 + wn * (BN / 2) + nt * 32 + (l31 & ~3); };
+        igemm_epilogue_vec<2, NT>(p, acc, lane, bsmp, mrow, orow, ncol);
     } else {
     float bv[NT];
     int ncol[NT];
@@ -574,6 +543,11 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
         }
     }
     const int mtiles = (int)((p.M + BM - 1) / BM);
+    static const int log_shapes = debug_switch("DPC_IGEMM_LOG", 0);
+    if (log_shapes)
+        fprintf(stderr, "igemm M=%lld C0=%d C1=%d N=%d taps=%d(%d) img=%dx%d->%dx%d F=%d out_mode=%d resid=%d ln=%d gn=%d a0s=%d\n", p.M, p.C0, p.C1,
+                p.N, p.ntaps, p_in.ntaps, p.Hi, p.Wi, p.Ho, p.Wo, p.F, p.out_mode, p.resid != nullptr, p.ln_stats != nullptr, p.gn_raw != nullptr,
+                p.a0_stride);
     const double flops = 2.0 * (double)p.M * p.N * (double)p_in.ntaps * (p.C0 + p.C1);      // algorithmic: all taps of the operator
     const double bytes = 4.0 * ((double)p.M * (p.N + (p.resid ? p.N : 0)) + (double)p.BF * p.Hi * p.Wi * (p.C0 + p.C1) +
                                 (double)p.ntaps * (p.C0 + p.C1) * p.N);
@@ -586,6 +560,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
     if (igemm_mode_default() == 2) {
         const size_t lds3 = 2 * (size_t)g3::BM * g3::RS;
+        if (igemm3p_supported(p)) return launch_igemm3p(p, wp6, s);      // 1-tap, K <= 256: 64-row panels over all N (igemm_panel.hip)
         // split-K for the GEMM-shaped deep levels of the 2-D U-Net (K x taps >= 4096: few row tiles, hundreds of iterations;
         // 256 workgroups leave three quarters of the 4-per-CU slots empty): four slices of the iteration range run as
         // separate workgroups, a second kernel adds them in fixed order.  The rule looks at the reduction length only, never
@@ -671,9 +646,13 @@ __global__ void pack_weights_g6_kernel(const float* __restrict__ w, unsigned sho
             v = g3::sat16(v);
             const unsigned h1 = g3::cvt_pk_f16(v, 0.f) & 0xffffu;
             const unsigned h2 = g3::cvt_pk_f16(v - (float)__builtin_bit_cast(g3::f16x2_g, h1).x, 0.f) & 0xffffu;
-            unsigned short* d3 = wp + (((long long)tap * kchunks + kc) * Npad + n) * 64 + kk;
+            // fragment order (r03): per iteration [32-column block][k-step 2][plane 2][half 2][n 32][8 fp16] -- the 16 bytes lane
+            // (n, half) feeds to one MFMA are contiguous ACROSS the wave (1 KB per fragment load = 8 cache lines instead of 32 lines
+            // of the former [n][plane][32 k] rows), and a 32-column block's four fragments are one 4 KB run (igemm_wide's LDS image)
+            const int ks = kk >> 4, hf = (kk >> 3) & 1, j = kk & 7;
+            unsigned short* d3 = wp + ((long long)tap * kchunks + kc) * Npad * 64 + ((n >> 5) * 4 + ks * 2) * 512 + hf * 256 + (n & 31) * 8 + j;
             d3[0] = (unsigned short)h1;
-            d3[32] = (unsigned short)h2;
+            d3[512] = (unsigned short)h2;
             continue;
         }
         const unsigned p1 = g6::cvt_pk_bf16(v, 0.f) & 0xffffu;

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "f16x3.h"
+#include "igemm_epilogue.h"
 
 namespace dpc {
 
@@ -44,9 +45,8 @@ struct WStage {             // one chunk in flight: 2 activation rows x 8 channe
 //   A  [row 256][144 B]: plane 0 at +0, plane 1 at +64; a fragment read (lane = row, 16 B) walks 9 slots per row -> the 16-lane
 //      groups of ds_read_b128 hit 16 different slots; a thread writes 8 channels = 16 B per plane, and the 8 lanes of a
 //      ds_write_b128 group hold 8 CONSECUTIVE ROWS of one column piece (slots 9 r + j: distinct mod 8).
-//   B  [k-step 2][plane 2][32-column block 4][half 2][n 32][16 B]: a fragment read covers 1 KB contiguously; the copy-in gives the
-//      8 lanes of a write group 8 consecutive columns of one 16-byte piece, while one load instruction still covers 8 whole
-//      128-byte weight rows (lane = piece * 8 + column).
+//   B  [32-column block 4][k-step 2][plane 2][half 2][n 32][16 B] = the packed weights' own order (pack_weights_g6_kernel): a
+//      fragment read covers 1 KB contiguously and the copy-in is linear on both sides.
 template <bool SPLIT, int V>
 __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace gw;
@@ -89,11 +89,10 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
     const float* pa0[2] = {p.a0, p.a0};                          // this tap's pixel in source 0 / source 1 (row 0 when out of the image)
     const float* pa1[2] = {p.a1, p.a1};
     unsigned rok = 0;
-    // weights: load k (0, 1) of a thread = column wave * 16 + k * 8 + lane % 8, 16-byte piece lane / 8 = plane * 4 + k-step * 2 + half
-    const int piece = lane >> 3;
-    const int bcol = wave * 16 + (lane & 7);
-    const unsigned char* wsrc = wp6 + ((long long)n0 + bcol) * WROW + piece * 16;
-    const int bdst = ((((piece >> 1) & 1) * 2 + (piece >> 2)) * 4 + (bcol >> 5)) * 1024 + (piece & 1) * 512 + (bcol & 31) * 16;
+    // weights: the tile's 128 columns of one iteration are 16 KB contiguous in the pack, already in fragment order: a straight copy,
+    // thread t moves bytes [16 t, 16 t + 16) and [8192 + 16 t, ..) (1 KB per wave instruction on both sides, conflict-free writes)
+    const unsigned char* wsrc = wp6 + (long long)(n0 >> 5) * 4096 + tid * 16;
+    const int bdst = tid * 16;
     const long long wstep = (long long)p.Npad * WROW;
     const int nit_all = p.ntaps * p.kchunks;
     const int nsl = SPLIT ? p.ksplit : 1;
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
         }
         const unsigned char* ws = wsrc + (long long)it * wstep;
         st.b[0] = *reinterpret_cast<const uint4*>(ws);
-        st.b[1] = *reinterpret_cast<const uint4*>(ws + 8 * WROW);
+        st.b[1] = *reinterpret_cast<const uint4*>(ws + 8192);
     };
     auto stash = [&](const WStage& st, int buf) {
         unsigned char* A = smem_w + buf * ABYTES;
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
             *reinterpret_cast<h3::f16x8*>(dst + 64) = pl[1];
         }
         *reinterpret_cast<uint4*>(B + bdst) = st.b[0];
-        *reinterpret_cast<uint4*>(B + bdst + 8 * 16) = st.b[1];
+        *reinterpret_cast<uint4*>(B + bdst + 8192) = st.b[1];
     };
 
     f32x16 acc[2][2];
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     const int a_lane = (wm * 64 + l31) * RS + hh * 16;
-    const int b_lane = wn * 2048 + hh * 512 + l31 * 16;
+    const int b_lane = wn * 8192 + hh * 512 + l31 * 16;
     // The matrix work trails the fragment reads by half a chunk: right after a barrier a wave issues the k-step-0 reads of the new
     // image and multiplies the k-step-1 fragments it read BEFORE the barrier (held in registers), so the LDS latency that follows
     // every barrier -- both waves of a SIMD leave it together -- is covered by 12 MFMAs instead of idling the matrix pipe.
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fb[nt][pl] = *reinterpret_cast<const f16x8_w*>(B + ((ks * 2 + pl) * 4 + nt) * 1024 + b_lane);
+            for (int pl = 0; pl < 2; ++pl) fb[nt][pl] = *reinterpret_cast<const f16x8_w*>(B + nt * 4096 + (ks * 2 + pl) * 1024 + b_lane);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -237,35 +236,10 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
             }
     } else {
         const int q3 = l31 & 3;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const long long m = m0 + wm * 64 + mt * 32 + 8 * g + 4 * hh + q3;
-                const long long orow = m * p.N;                   // (out_mode 0 only: see igemm3w_supported)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    float x[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = acc[mt][nt][4 * g + e];
-                    {
-                        const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-#define DPC_QUAD_XCHG(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
-                        const float r0 = DPC_QUAD_XCHG(b0 ? x[0] : x[1], 0xB1), r1 = DPC_QUAD_XCHG(b0 ? x[2] : x[3], 0xB1);
-                        const float y0 = b0 ? r0 : x[0], y1 = b0 ? x[1] : r0, y2 = b0 ? r1 : x[2], y3 = b0 ? x[3] : r1;
-                        const float s0_ = DPC_QUAD_XCHG(b1 ? y0 : y2, 0x4E), s1_ = DPC_QUAD_XCHG(b1 ? y1 : y3, 0x4E);
-#undef DPC_QUAD_XCHG
-                        x[0] = b1 ? s0_ : y0; x[2] = b1 ? y2 : s0_; x[1] = b1 ? s1_ : y1; x[3] = b1 ? y3 : s1_;
-                    }
-                    const int n = n0 + wn * 64 + nt * 32 + (l31 & ~3);
-                    if (m >= p.M || n >= p.N) continue;
-                    f32x4 v = f32x4{x[0], x[1], x[2], x[3]} * p.descale;
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.N + n);
-                    overflow_note4(p.oflag, v);
-                    *reinterpret_cast<f32x4*>(p.out + orow + n) = v;
-                }
-            }
+        auto mrow = [&](int mt, int g) { return m0 + wm * 64 + mt * 32 + 8 * g + 4 * hh + q3; };
+        auto orow = [&](int mt, int g) { return mrow(mt, g) * p.N; };            // (out_mode 0 only: see igemm3w_supported)
+        auto ncol = [&](int nt) { return n0 + wn * 64 + nt * 32 + (l31 & ~3); };
+        igemm_epilogue_vec<2, 2>(p, acc, lane, 0, mrow, orow, ncol);
     }
 }
 
@@ -273,7 +247,8 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
 bool igemm3w_supported(const IgemmParams& p) {
     static const int on = debug_switch("DPC_IGEMM_LDSB", 1);
     const int nit = p.ntaps * p.kchunks;
-    return on && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && !p.a0_stride && p.N % 4 == 0 && p.Npad % 128 == 0 && p.N >= 128 && nit >= 24;
+    static const int nit_min = debug_switch("DPC_IGEMM_WMIN", 24);
+    return on && nit >= nit_min && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && !p.a0_stride && p.N % 4 == 0 && p.Npad % 128 == 0 && p.N >= 128;
 }
 // split-K slices of the wide kernel: the deep levels have few rows and many columns (N = 512: 2, N >= 1024: 4), >= 12 chunks each
 int igemm3w_slices(const IgemmParams& p) {

@@ -27,6 +27,8 @@ BURGERS = [
 SMOKE = [
     ("s 16x16 256->256 1x1 +res", 512, 16, 16, 256, 0, 256, 1, True),
     ("s 16x16 256->384 1x1", 512, 16, 16, 256, 0, 384, 1, False),
+    ("s 16x16 256->384 1x1 LN", 512, 16, 16, 256, 0, 384, 1, "ln"),
+    ("s 16x16 128->256 1x1 +res", 512, 16, 16, 128, 0, 256, 1, True),
     ("s 32x32 128->128 1x1 +res", 512, 32, 32, 128, 0, 128, 1, True),
     ("s 32x32 256->128 1x1 (concat)", 512, 32, 32, 128, 128, 128, 1, False),
     ("s 64x64 128->64 1x1 (concat)", 512, 64, 64, 64, 64, 64, 1, False),
@@ -41,20 +43,24 @@ for name, images, H, W, C0, C1, N, k, res in shapes:
     a0 = torch.randn(images * H * W, C0, generator=g).to(dev)
     a1 = torch.randn(images * H * W, C1, generator=g).to(dev) if C1 else None
     bias = torch.randn(N, generator=g).to(dev)
-    resid = torch.randn(images * H * W, N, generator=g).to(dev) if res else None
+    resid = torch.randn(images * H * W, N, generator=g).to(dev) if res is True else None
+    ln = None
+    if res == "ln":
+        mu = a0.mean(1); inv = (a0.var(1, unbiased=False) + 1e-5).rsqrt()
+        ln = (torch.stack([mu, inv], 1).contiguous(), (1 + 0.1 * torch.randn(K, generator=g)).to(dev))
     c3 = SH._Conv(w, mode="f16x3")
     c6 = SH._Conv(w, mode="x6")
-    out3 = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid)
-    out6 = c6(a0, images, H, W, a1=a1, bias=bias, resid=resid)
+    out3 = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln)
+    out6 = c6(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln)
     torch.cuda.synchronize()
     err = float((out3 - out6).abs().max() / out6.abs().max())
-    out3b = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid)
+    out3b = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln)
     same = bool(torch.equal(out3, out3b))
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, out=out3)
+        c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, out=out3, ln=ln)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
@@ -62,6 +68,6 @@ for name, images, H, W, C0, C1, N, k, res in shapes:
     us = ts[len(ts) // 2]
     M = images * H * W
     flop = 2.0 * M * N * K * k * k
-    byts = 4.0 * (M * K + M * N * (2 if res else 1) + K * k * k * N)
+    byts = 4.0 * (M * K + M * N * (2 if res is True else 1) + K * k * k * N)
     print(f"{name:34s} M={M:7d} K={K * k * k:5d} N={N:4d}  {us:8.1f} us  {flop / us * 1e-6:7.1f} TF/s  {byts / us * 1e-6:6.2f} TB/s  "
           f"err {err:.2e}  repeatable {same}", flush=True)
