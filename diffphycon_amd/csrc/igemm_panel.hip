@@ -1,6 +1,7 @@
 // Row-panel form of the f16x3 implicit GEMM (igemm6.hip: igemm3_kernel) for the 1-tap operators with a short reduction: the
 // 1x1x1 projections of the attention blocks (to_qkv behind a channel LayerNorm, to_out + residual) and the res_conv of a ResnetBlock
-// (video_diffusion_pytorch_conv3d.py:159-163, 206-230, 232-257; burgers_1d/unet.py the same).  K <= 256, N in {64, 128, 256, 384}.
+// (video_diffusion_pytorch_conv3d.py:159-163, 206-230, 232-257; burgers_1d/unet.py the same), K <= 256, N in {64, 128, 256, 384}; and
+// (TAPS form) for few-tap operators whose im2col row is <= 256 wide: the 2 x 2-tap parity classes of ConvTranspose3d at 64 channels.
 //
 // Why: igemm3's 128 x 64 tiles walk K in 32-channel chunks -- each chunk is one dependent round trip to memory behind a barrier
 // (r03 PMC: waves 56-69 % of their cycles in s_waitcnt, 5 us per chunk), every 128-byte piece of an activation row is fetched in a
@@ -31,7 +32,7 @@ constexpr int WROW = 128;                   // packed weight bytes per output ch
 typedef _Float16 f16x8_p __attribute__((ext_vector_type(8)));
 
 // KC: 32-channel chunks of the (zero-padded) reduction; wave grid WM x WN (4 waves), wave tile MT x NT blocks of 32 x 32
-template <int KC, int MT, int NT, int WM, int WN>
+template <int KC, int MT, int NT, int WM, int WN, bool TAPS>
 __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace gpn;
     static_assert(WM * WN == 4 && WM * MT * 32 == BM, "64-row panel, four waves");
@@ -50,22 +51,56 @@ __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const un
     f32x4 lg[GPT][2];                                             // LayerNorm gamma of the group's channels
     float lmean[GPT], linv[GPT];
     bool ok[GPT];
+    if constexpr (!TAPS) {
 #pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-        const int g = tid + 256 * j;
-        const int row = g / GPR, c = (g % GPR) * 8;
-        const long long m = m0 + row;
-        ok[j] = m < p.M && c < K;
-        const long long mm = ok[j] ? m : 0;
-        const int cc = ok[j] ? c : 0;
-        const float* src = cc < p.C0 ? p.a0 + mm * p.C0 + cc : p.a1 + mm * p.C1 + (cc - p.C0);
-        v[j][0] = *reinterpret_cast<const f32x4*>(src);
-        v[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
-        if (p.ln_stats) {
-            lmean[j] = p.ln_stats[2 * mm];
-            linv[j] = p.ln_stats[2 * mm + 1];
-            lg[j][0] = *reinterpret_cast<const f32x4*>(p.ln_gamma + cc);
-            lg[j][1] = *reinterpret_cast<const f32x4*>(p.ln_gamma + cc + 4);
+        for (int j = 0; j < GPT; ++j) {
+            const int g = tid + 256 * j;
+            const int row = g / GPR, c = (g % GPR) * 8;
+            const long long m = m0 + row;
+            ok[j] = m < p.M && c < K;
+            const long long mm = ok[j] ? m : 0;
+            const int cc = ok[j] ? c : 0;
+            const float* src = cc < p.C0 ? p.a0 + mm * p.C0 + cc : p.a1 + mm * p.C1 + (cc - p.C0);
+            v[j][0] = *reinterpret_cast<const f32x4*>(src);
+            v[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            if (p.ln_stats) {
+                lmean[j] = p.ln_stats[2 * mm];
+                linv[j] = p.ln_stats[2 * mm + 1];
+                lg[j][0] = *reinterpret_cast<const f32x4*>(p.ln_gamma + cc);
+                lg[j][1] = *reinterpret_cast<const f32x4*>(p.ln_gamma + cc + 4);
+            }
+        }
+    } else {
+        // several taps: the panel row of output point m is the concatenation over the taps of the shifted input pixels (the im2col
+        // row, chunk index = tap * kchunks + kc as in the pack).  A thread's column group -- hence its tap and channels -- is the
+        // same for all its rows (rows tid / GPR + (256 / GPR) j): one (frame, y, x) decomposition, then carries.
+        constexpr int RSTEP = 256 / GPR;
+        const int cg = tid % GPR, it = cg >> 2;
+        const int tap = it / p.kchunks, kc = it - tap * p.kchunks;
+        const int c = kc * 32 + (cg & 3) * 8;
+        const int df = p.tdf[tap], dh = p.tdh[tap], dw = p.tdw[tap];
+        const int HoWo = p.Ho * p.Wo;
+        const long long mfirst = m0 + tid / GPR;
+        long long bf = mfirst / HoWo;
+        int hw = (int)(mfirst - bf * HoWo);
+        int ho = hw / p.Wo, wo = hw - ho * p.Wo;
+        int fr = (int)(bf % p.F);
+        const bool cok = c < K && tap < p.ntaps;
+        const float* base = c < p.C0 ? p.a0 + c : p.a1 + (c - p.C0);
+        const int cs = c < p.C0 ? p.C0 : p.C1;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const long long m = mfirst + RSTEP * j;
+            const int fi = fr + df, hi = ho * p.sh + dh, wi = wo * p.sw + dw;
+            ok[j] = cok && m < p.M && (unsigned)fi < (unsigned)p.F && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            const long long px = ok[j] ? ((bf + df) * p.Hi + hi) * p.Wi + wi : 0;
+            const float* src = ok[j] ? base + px * cs : p.a0;
+            v[j][0] = *reinterpret_cast<const f32x4*>(src);
+            v[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            wo += RSTEP;
+            while (wo >= p.Wo) { wo -= p.Wo; ++ho; }
+            while (ho >= p.Ho) { ho -= p.Ho; ++bf; ++fr; }
+            while (fr >= p.F) fr -= p.F;
         }
     }
     // weight fragments: [chunk][Npad / 32][k-step][plane][half][n 32][16 B]; lane (n = l31, half hh): 1 KB contiguous per load
@@ -88,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const un
         const int g = tid + 256 * j;
         const int row = g / GPR, c = (g % GPR) * 8;
         f32x4 a = v[j][0], b = v[j][1];
-        if (p.ln_stats) {
+        if (!TAPS && p.ln_stats) {
             a = (a - lmean[j]) * linv[j] * lg[j][0];
             b = (b - lmean[j]) * linv[j] * lg[j][1];
         }
@@ -148,49 +183,68 @@ __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const un
     const int q3 = l31 & 3;
     const long long bsmp = p.gn_raw ? m0 / p.gn_rows : 0;         // fused GroupNorm-apply residual: the panel lies inside one sample
     auto mrow = [&](int mt, int g) { return m0 + wm * MT * 32 + mt * 32 + 8 * g + 4 * hh + q3; };     // this lane's row after the transpose
-    auto orow = [&](int mt, int g) { return mrow(mt, g) * p.N; };
+    auto orow = [&](int mt, int g) -> long long {
+        const long long m = mrow(mt, g);
+        if (!TAPS || p.out_mode == 0) return m * p.N;
+        const long long mm = m < p.M ? m : 0;                      // ConvTranspose parity scatter into [BF][2 Ho][2 Wo][N]
+        const int HoWo = p.Ho * p.Wo;
+        const long long bf = mm / HoWo;
+        const int hw = (int)(mm - bf * HoWo), ho = hw / p.Wo, wo = hw - ho * p.Wo;
+        return ((bf * (2 * p.Ho) + 2 * ho + p.par_a) * (long long)(2 * p.Wo) + 2 * wo + p.par_b) * p.N;
+    };
     auto ncol = [&](int nt) { return wn * NT * 32 + nt * 32 + (l31 & ~3); };
     igemm_epilogue_vec<MT, NT>(p, acc, lane, bsmp, mrow, orow, ncol);
 }
 
-// shape-only rule (never the batch)
-bool igemm3p_supported(const IgemmParams& p) {
+// shape-only rules (never the batch).  1: one tap at offset 0 (the lean path); 2: several taps / strides, tap-major im2col panel
+static int panel_kind(const IgemmParams& p) {
     static const int on = debug_switch("DPC_IGEMM_PANEL", 1);
     const int K = p.C0 + p.C1;
-    return on && p.ntaps == 1 && p.tdf[0] == 0 && p.tdh[0] == 0 && p.tdw[0] == 0 && p.sh == 1 && p.sw == 1 && p.Hi == p.Ho && p.Wi == p.Wo &&
-           p.out_mode == 0 && !p.a0_stride && K <= 256 && (p.kchunks == 2 || p.kchunks == 4 || p.kchunks == 8) && p.C0 % 8 == 0 && p.C1 % 8 == 0 && p.N == p.Npad &&
-           (p.N == 64 || p.N == 128 || p.N == 256 || p.N == 384) && (!p.gn_raw || p.gn_rows % gpn::BM == 0);
+    const int kc_all = p.ntaps * p.kchunks;
+    if (!on || p.a0_stride || p.C0 % 8 || p.C1 % 8 || p.N != p.Npad || !(p.N == 64 || p.N == 128 || p.N == 256 || p.N == 384)) return 0;
+    if (!(kc_all == 2 || kc_all == 4 || kc_all == 8)) return 0;
+    if (p.gn_raw && (p.gn_rows % gpn::BM != 0 || p.out_mode != 0)) return 0;
+    const bool plain = p.ntaps == 1 && p.tdf[0] == 0 && p.tdh[0] == 0 && p.tdw[0] == 0 && p.sh == 1 && p.sw == 1 && p.Hi == p.Ho && p.Wi == p.Wo;
+    if (plain && p.out_mode == 0 && K <= 256) return 1;
+    if (!p.ln_stats && (p.out_mode == 0 || p.out_mode == 2) && p.Wo >= 1 && p.Ho >= 1) return 2;
+    return 0;
 }
+bool igemm3p_supported(const IgemmParams& p) { return panel_kind(p) != 0; }
 
-template <int KC, int MT, int NT, int WM, int WN>
+template <int KC, int MT, int NT, int WM, int WN, bool TAPS>
 static int launch_p(const IgemmParams& p, const void* wp6, hipStream_t s) {
     constexpr int LDS = gpn::BM * (KC * 128 + 16);
     static DeviceOnce once;
     if (!once) {
-        DPC_HIP(hipFuncSetAttribute((const void*)igemm3p_kernel<KC, MT, NT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        DPC_HIP(hipFuncSetAttribute((const void*)igemm3p_kernel<KC, MT, NT, WM, WN, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         once = true;
     }
     const unsigned nwg = (unsigned)((p.M + gpn::BM - 1) / gpn::BM);
-    hipLaunchKernelGGL((igemm3p_kernel<KC, MT, NT, WM, WN>), dim3(nwg), dim3(256), LDS, s, p, (const unsigned char*)wp6);
+    hipLaunchKernelGGL((igemm3p_kernel<KC, MT, NT, WM, WN, TAPS>), dim3(nwg), dim3(256), LDS, s, p, (const unsigned char*)wp6);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
 
-template <int KC>
+template <int KC, bool TAPS>
 static int launch_pk(const IgemmParams& p, const void* wp6, hipStream_t s) {
     switch (p.N) {
-        case 384: return launch_p<KC, 2, 3, 1, 4>(p, wp6, s);
-        case 256: return launch_p<KC, 2, 2, 1, 4>(p, wp6, s);
-        case 128: return launch_p<KC, 1, 2, 2, 2>(p, wp6, s);
-        default: return launch_p<KC, 1, 1, 2, 2>(p, wp6, s);
+        case 384: return launch_p<KC, 2, 3, 1, 4, TAPS>(p, wp6, s);
+        case 256: return launch_p<KC, 2, 2, 1, 4, TAPS>(p, wp6, s);
+        case 128: return launch_p<KC, 1, 2, 2, 2, TAPS>(p, wp6, s);
+        default: return launch_p<KC, 1, 1, 2, 2, TAPS>(p, wp6, s);
     }
 }
 
 int launch_igemm3p(const IgemmParams& p, const void* wp6, hipStream_t s) {
-    const int kc = p.kchunks;
-    if (kc <= 2) return launch_pk<2>(p, wp6, s);
-    if (kc <= 4) return launch_pk<4>(p, wp6, s);
-    return launch_pk<8>(p, wp6, s);
+    const int kc = p.ntaps * p.kchunks;
+    if (panel_kind(p) == 1) {
+        if (kc <= 2) return launch_pk<2, false>(p, wp6, s);
+        if (kc <= 4) return launch_pk<4, false>(p, wp6, s);
+        return launch_pk<8, false>(p, wp6, s);
+    }
+    if (kc <= 2) return launch_pk<2, true>(p, wp6, s);
+    if (kc <= 4) return launch_pk<4, true>(p, wp6, s);
+    return launch_pk<8, true>(p, wp6, s);
 }
 
 }  // namespace dpc

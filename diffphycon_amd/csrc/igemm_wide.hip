@@ -25,12 +25,11 @@
 namespace dpc {
 
 namespace gw {
-constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int BM = 256, BK = 32;
 constexpr int RS = 144;                     // LDS bytes per A row (2 planes x 64 B + 16 pad), as igemm3
 constexpr int WROW = 128;                   // packed weight bytes per output channel per iteration
-constexpr int ABYTES = BM * RS, BBYTES = BN * WROW;
-constexpr int TAPOFF = 2 * (ABYTES + BBYTES);
-constexpr int LDS = TAPOFF + 32 * 4;
+constexpr int ABYTES = BM * RS;
+constexpr int lds_bytes(int bn) { return 2 * (ABYTES + bn * WROW) + 32 * 4; }
 }  // namespace gw
 
 typedef _Float16 f16x8_w __attribute__((ext_vector_type(8)));
@@ -47,12 +46,16 @@ struct WStage {             // one chunk in flight: 2 activation rows x 8 channe
 //      ds_write_b128 group hold 8 CONSECUTIVE ROWS of one column piece (slots 9 r + j: distinct mod 8).
 //   B  [32-column block 4][k-step 2][plane 2][half 2][n 32][16 B] = the packed weights' own order (pack_weights_g6_kernel): a
 //      fragment read covers 1 KB contiguously and the copy-in is linear on both sides.
-template <bool SPLIT, int V>
+// BN = 128: 8 waves as 4 x 2, 64 x 64 each; BN = 64 (r03: the 64-column stride-2 down convolutions and other long reductions into
+// 64 columns): 8 waves as 8 x 1, 32 x 64 each
+template <bool SPLIT, int BN>
 __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace gw;
+    constexpr int BBYTES = BN * WROW, TAPOFF = 2 * (ABYTES + BBYTES);
+    constexpr int MT = BN == 128 ? 2 : 1;                         // 32-row blocks per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0, l31 = lane & 31, hh = lane >> 5;
     const int ntn = p.Npad / BN;
     const int mtiles = (int)((p.M + BM - 1) / BM);
     int bid = blockIdx.x;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
         }
         const unsigned char* ws = wsrc + (long long)it * wstep;
         st.b[0] = *reinterpret_cast<const uint4*>(ws);
-        st.b[1] = *reinterpret_cast<const uint4*>(ws + 8192);
+        if constexpr (BN == 128) st.b[1] = *reinterpret_cast<const uint4*>(ws + 8192);
     };
     auto stash = [&](const WStage& st, int buf) {
         unsigned char* A = smem_w + buf * ABYTES;
@@ -150,23 +153,23 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
             *reinterpret_cast<h3::f16x8*>(dst + 64) = pl[1];
         }
         *reinterpret_cast<uint4*>(B + bdst) = st.b[0];
-        *reinterpret_cast<uint4*>(B + bdst + 8192) = st.b[1];
+        if constexpr (BN == 128) *reinterpret_cast<uint4*>(B + bdst + 8192) = st.b[1];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    const int a_lane = (wm * 64 + l31) * RS + hh * 16;
+    const int a_lane = (wm * MT * 32 + l31) * RS + hh * 16;
     const int b_lane = wn * 8192 + hh * 512 + l31 * 16;
     // The matrix work trails the fragment reads by half a chunk: right after a barrier a wave issues the k-step-0 reads of the new
     // image and multiplies the k-step-1 fragments it read BEFORE the barrier (held in registers), so the LDS latency that follows
     // every barrier -- both waves of a SIMD leave it together -- is covered by 12 MFMAs instead of idling the matrix pipe.
-    f16x8_w fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];      // [mt | nt][plane] of k-step 0 / 1
-    auto read_frags = [&](int buf, int ks, f16x8_w (&fa)[2][2], f16x8_w (&fb)[2][2]) {
+    f16x8_w fa0[MT][2], fb0[2][2], fa1[MT][2], fb1[2][2];      // [mt | nt][plane] of k-step 0 / 1
+    auto read_frags = [&](int buf, int ks, f16x8_w (&fa)[MT][2], f16x8_w (&fb)[2][2]) {
         const unsigned char* A = smem_w + buf * ABYTES;
         const unsigned char* B = smem_w + 2 * ABYTES + buf * BBYTES;
 #pragma unroll
@@ -174,16 +177,16 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) fb[nt][pl] = *reinterpret_cast<const f16x8_w*>(B + nt * 4096 + (ks * 2 + pl) * 1024 + b_lane);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) fa[mt][pl] = *reinterpret_cast<const f16x8_w*>(A + a_lane + mt * 32 * RS + pl * 64 + ks * 32);
     };
-    auto mfma12 = [&](const f16x8_w (&fa)[2][2], const f16x8_w (&fb)[2][2]) {
+    auto mfma12 = [&](const f16x8_w (&fa)[MT][2], const f16x8_w (&fb)[2][2]) {
         constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};         // small terms first (as igemm3)
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][PA[term]], fb[nt][PB[term]], acc[mt][nt], 0, 0, 0);
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
     if constexpr (SPLIT) {             // raw partial accumulators [slice][M][N]; finished by igemm3_reduce_kernel
         float* pb = p.part + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const long long m = m0 + wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (m >= p.M) continue;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
@@ -236,19 +239,19 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
             }
     } else {
         const int q3 = l31 & 3;
-        auto mrow = [&](int mt, int g) { return m0 + wm * 64 + mt * 32 + 8 * g + 4 * hh + q3; };
+        auto mrow = [&](int mt, int g) { return m0 + wm * MT * 32 + mt * 32 + 8 * g + 4 * hh + q3; };
         auto orow = [&](int mt, int g) { return mrow(mt, g) * p.N; };            // (out_mode 0 only: see igemm3w_supported)
         auto ncol = [&](int nt) { return n0 + wn * 64 + nt * 32 + (l31 & ~3); };
-        igemm_epilogue_vec<2, 2>(p, acc, lane, 0, mrow, orow, ncol);
+        igemm_epilogue_vec<MT, 2>(p, acc, lane, 0, mrow, orow, ncol);
     }
 }
 
-// shape-only rules (never the batch): long reductions into >= 128 columns, plain [M][N] output
+// shape-only rules (never the batch): long reductions, plain [M][N] output; 128-column tiles when Npad allows, else 64
 bool igemm3w_supported(const IgemmParams& p) {
     static const int on = debug_switch("DPC_IGEMM_LDSB", 1);
     const int nit = p.ntaps * p.kchunks;
     static const int nit_min = debug_switch("DPC_IGEMM_WMIN", 24);
-    return on && nit >= nit_min && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && !p.a0_stride && p.N % 4 == 0 && p.Npad % 128 == 0 && p.N >= 128;
+    return on && nit >= nit_min && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && !p.a0_stride && p.N % 4 == 0 && p.Npad % 64 == 0 && p.N >= 64;
 }
 // split-K slices of the wide kernel: the deep levels have few rows and many columns (N = 512: 2, N >= 1024: 4), >= 12 chunks each
 int igemm3w_slices(const IgemmParams& p) {
@@ -258,34 +261,26 @@ int igemm3w_slices(const IgemmParams& p) {
     return nsl;
 }
 
-template <int V>
-static int launch_w(const IgemmParams& p, const void* wp6, int nsl, unsigned nwg, hipStream_t s) {
+template <int BN>
+static int launch_w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s) {
     using namespace gw;
+    constexpr int LDS = lds_bytes(BN);
     static DeviceOnce once;
     if (!once) {
-        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<true, V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        DPC_HIP(hipFuncSetAttribute((const void*)igemm3w_kernel<false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         once = true;
     }
-    if (nsl > 1) hipLaunchKernelGGL((igemm3w_kernel<true, V>), dim3(nwg, nsl), dim3(512), LDS, s, p, (const unsigned char*)wp6);
-    else hipLaunchKernelGGL((igemm3w_kernel<false, V>), dim3(nwg), dim3(512), LDS, s, p, (const unsigned char*)wp6);
+    const int mtiles = (int)((p.M + BM - 1) / BM);
+    const unsigned nwg = (unsigned)mtiles * (p.Npad / BN);
+    if (nsl > 1) hipLaunchKernelGGL((igemm3w_kernel<true, BN>), dim3(nwg, nsl), dim3(512), LDS, s, p, (const unsigned char*)wp6);
+    else hipLaunchKernelGGL((igemm3w_kernel<false, BN>), dim3(nwg), dim3(512), LDS, s, p, (const unsigned char*)wp6);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
 
 int launch_igemm3w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s) {
-    using namespace gw;
-    const int mtiles = (int)((p.M + BM - 1) / BM);
-    const unsigned nwg = (unsigned)mtiles * (p.Npad / BN);
-    static const int v = debug_switch("DPC_IGEMM_WV", 0);
-    switch (v) {
-        case 1: return launch_w<1>(p, wp6, nsl, nwg, s);
-        case 2: return launch_w<2>(p, wp6, nsl, nwg, s);
-        case 3: return launch_w<3>(p, wp6, nsl, nwg, s);
-        case 4: return launch_w<4>(p, wp6, nsl, nwg, s);
-        case 5: return launch_w<5>(p, wp6, nsl, nwg, s);
-        default: return launch_w<0>(p, wp6, nsl, nwg, s);
-    }
+    return p.Npad % 128 == 0 ? launch_w<128>(p, wp6, nsl, s) : launch_w<64>(p, wp6, nsl, s);
 }
 
 }  // namespace dpc

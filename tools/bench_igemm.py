@@ -34,6 +34,9 @@ SMOKE = [
     ("s 64x64 128->64 1x1 (concat)", 512, 64, 64, 64, 64, 64, 1, False),
     ("s 64x64 64->64 1x1 +res", 512, 64, 64, 64, 0, 64, 1, True),
     ("s 64x64 64->384 1x1", 512, 64, 64, 64, 0, 384, 1, False),
+    ("s 32x32 64->64 2x2 (ConvT class)", 512, 32, 32, 64, 0, 64, 2, False),
+    ("s 16x16 128->128 2x2 (ConvT class)", 512, 16, 16, 128, 0, 128, 2, False),
+    ("s 64x64->32x32 64->64 4x4 s2", 512, 64, 64, 64, 0, 64, 4, False),
 ]
 shapes = (BURGERS if which in ("burgers", "all") else []) + (SMOKE if which in ("smoke", "all") else [])
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -43,30 +46,32 @@ for name, images, H, W, C0, C1, N, k, res in shapes:
     a0 = torch.randn(images * H * W, C0, generator=g).to(dev)
     a1 = torch.randn(images * H * W, C1, generator=g).to(dev) if C1 else None
     bias = torch.randn(N, generator=g).to(dev)
-    resid = torch.randn(images * H * W, N, generator=g).to(dev) if res is True else None
+    resid = torch.randn(images * (H // 2 if k == 4 else H) * (W // 2 if k == 4 else W), N, generator=g).to(dev) if res is True else None
     ln = None
     if res == "ln":
         mu = a0.mean(1); inv = (a0.var(1, unbiased=False) + 1e-5).rsqrt()
         ln = (torch.stack([mu, inv], 1).contiguous(), (1 + 0.1 * torch.randn(K, generator=g)).to(dev))
-    c3 = SH._Conv(w, mode="f16x3")
-    c6 = SH._Conv(w, mode="x6")
-    out3 = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln)
-    out6 = c6(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln)
+    kw = dict(sh=2, sw=2, ph=1, pw=1) if k == 4 else {}
+    Ho, Wo = (H // 2, W // 2) if k == 4 else (H, W)
+    c3 = SH._Conv(w, mode="f16x3", **kw)
+    c6 = SH._Conv(w, mode="x6", **kw)
+    out3 = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln, Ho=Ho, Wo=Wo)
+    out6 = c6(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln, Ho=Ho, Wo=Wo)
     torch.cuda.synchronize()
     err = float((out3 - out6).abs().max() / out6.abs().max())
-    out3b = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln)
+    out3b = c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, ln=ln, Ho=Ho, Wo=Wo)
     same = bool(torch.equal(out3, out3b))
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, out=out3, ln=ln)
+        c3(a0, images, H, W, a1=a1, bias=bias, resid=resid, out=out3, ln=ln, Ho=Ho, Wo=Wo)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     us = ts[len(ts) // 2]
-    M = images * H * W
+    M = images * Ho * Wo
     flop = 2.0 * M * N * K * k * k
     byts = 4.0 * (M * K + M * N * (2 if res is True else 1) + K * k * k * N)
     print(f"{name:34s} M={M:7d} K={K * k * k:5d} N={N:4d}  {us:8.1f} us  {flop / us * 1e-6:7.1f} TF/s  {byts / us * 1e-6:6.2f} TB/s  "
