@@ -25,17 +25,17 @@
 namespace dpc {
 
 namespace gpn {
-constexpr int BM = 64;
 constexpr int WROW = 128;                   // packed weight bytes per output channel per 32-channel chunk
 }  // namespace gpn
 
 typedef _Float16 f16x8_p __attribute__((ext_vector_type(8)));
 
 // KC: 32-channel chunks of the (zero-padded) reduction; wave grid WM x WN (4 waves), wave tile MT x NT blocks of 32 x 32
-template <int KC, int MT, int NT, int WM, int WN, bool TAPS>
+// BM: panel rows (64; 32 for the 16-chunk im2col rows of the 128-channel ConvTranspose classes: 66 KB of LDS either way)
+template <int KC, int MT, int NT, int WM, int WN, bool TAPS, int BM>
 __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
     using namespace gpn;
-    static_assert(WM * WN == 4 && WM * MT * 32 == BM, "64-row panel, four waves");
+    static_assert(WM * WN == 4 && WM * MT * 32 == BM, "four waves cover the panel");
     constexpr int KP = KC * 32;                                   // padded K
     constexpr int PITCH = KP * 4 + 16;                            // bytes per LDS row: plane 0 (KP fp16) | plane 1 | pad
     constexpr int GPR = KP / 8;                                   // 8-channel groups per row
@@ -202,36 +202,44 @@ static int panel_kind(const IgemmParams& p) {
     const int K = p.C0 + p.C1;
     const int kc_all = p.ntaps * p.kchunks;
     if (!on || p.a0_stride || p.C0 % 8 || p.C1 % 8 || p.N != p.Npad || !(p.N == 64 || p.N == 128 || p.N == 256 || p.N == 384)) return 0;
-    if (!(kc_all == 2 || kc_all == 4 || kc_all == 8)) return 0;
-    if (p.gn_raw && (p.gn_rows % gpn::BM != 0 || p.out_mode != 0)) return 0;
+    if (!(kc_all == 2 || kc_all == 4 || kc_all == 8 || (kc_all == 16 && p.N >= 128))) return 0;
+    if (p.gn_raw && (p.gn_rows % 64 != 0 || p.out_mode != 0)) return 0;
     const bool plain = p.ntaps == 1 && p.tdf[0] == 0 && p.tdh[0] == 0 && p.tdw[0] == 0 && p.sh == 1 && p.sw == 1 && p.Hi == p.Ho && p.Wi == p.Wo;
-    if (plain && p.out_mode == 0 && K <= 256) return 1;
+    if (plain && p.out_mode == 0 && K <= 512) return 1;
     if (!p.ln_stats && (p.out_mode == 0 || p.out_mode == 2) && p.Wo >= 1 && p.Ho >= 1) return 2;
     return 0;
 }
 bool igemm3p_supported(const IgemmParams& p) { return panel_kind(p) != 0; }
 
-template <int KC, int MT, int NT, int WM, int WN, bool TAPS>
+template <int KC, int MT, int NT, int WM, int WN, bool TAPS, int BM>
 static int launch_p(const IgemmParams& p, const void* wp6, hipStream_t s) {
-    constexpr int LDS = gpn::BM * (KC * 128 + 16);
+    constexpr int LDS = BM * (KC * 128 + 16);
     static DeviceOnce once;
     if (!once) {
-        DPC_HIP(hipFuncSetAttribute((const void*)igemm3p_kernel<KC, MT, NT, WM, WN, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        DPC_HIP(hipFuncSetAttribute((const void*)igemm3p_kernel<KC, MT, NT, WM, WN, TAPS, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         once = true;
     }
-    const unsigned nwg = (unsigned)((p.M + gpn::BM - 1) / gpn::BM);
-    hipLaunchKernelGGL((igemm3p_kernel<KC, MT, NT, WM, WN, TAPS>), dim3(nwg), dim3(256), LDS, s, p, (const unsigned char*)wp6);
+    const unsigned nwg = (unsigned)((p.M + BM - 1) / BM);
+    hipLaunchKernelGGL((igemm3p_kernel<KC, MT, NT, WM, WN, TAPS, BM>), dim3(nwg), dim3(256), LDS, s, p, (const unsigned char*)wp6);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }
 
 template <int KC, bool TAPS>
 static int launch_pk(const IgemmParams& p, const void* wp6, hipStream_t s) {
-    switch (p.N) {
-        case 384: return launch_p<KC, 2, 3, 1, 4, TAPS>(p, wp6, s);
-        case 256: return launch_p<KC, 2, 2, 1, 4, TAPS>(p, wp6, s);
-        case 128: return launch_p<KC, 1, 2, 2, 2, TAPS>(p, wp6, s);
-        default: return launch_p<KC, 1, 1, 2, 2, TAPS>(p, wp6, s);
+    if constexpr (KC == 16) {            // 32-row panels, waves 1 x 4
+        switch (p.N) {
+            case 384: return launch_p<KC, 1, 3, 1, 4, TAPS, 32>(p, wp6, s);
+            case 256: return launch_p<KC, 1, 2, 1, 4, TAPS, 32>(p, wp6, s);
+            default: return launch_p<KC, 1, 1, 1, 4, TAPS, 32>(p, wp6, s);
+        }
+    } else {
+        switch (p.N) {
+            case 384: return launch_p<KC, 2, 3, 1, 4, TAPS, 64>(p, wp6, s);
+            case 256: return launch_p<KC, 2, 2, 1, 4, TAPS, 64>(p, wp6, s);
+            case 128: return launch_p<KC, 1, 2, 2, 2, TAPS, 64>(p, wp6, s);
+            default: return launch_p<KC, 1, 1, 2, 2, TAPS, 64>(p, wp6, s);
+        }
     }
 }
 
@@ -240,11 +248,13 @@ int launch_igemm3p(const IgemmParams& p, const void* wp6, hipStream_t s) {
     if (panel_kind(p) == 1) {
         if (kc <= 2) return launch_pk<2, false>(p, wp6, s);
         if (kc <= 4) return launch_pk<4, false>(p, wp6, s);
-        return launch_pk<8, false>(p, wp6, s);
+        if (kc <= 8) return launch_pk<8, false>(p, wp6, s);
+        return launch_pk<16, false>(p, wp6, s);
     }
     if (kc <= 2) return launch_pk<2, true>(p, wp6, s);
     if (kc <= 4) return launch_pk<4, true>(p, wp6, s);
-    return launch_pk<8, true>(p, wp6, s);
+    if (kc <= 8) return launch_pk<8, true>(p, wp6, s);
+    return launch_pk<16, true>(p, wp6, s);
 }
 
 }  // namespace dpc

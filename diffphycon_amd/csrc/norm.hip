@@ -210,17 +210,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
     const long long rpb = (R + nblk - 1) / nblk;
     const long long r_begin = blockIdx.x * rpb, r_end = min(R, r_begin + rpb);
     unsigned omx = 0;
-    for (long long r = r_begin + rsub; r < r_end; r += rpp) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
+    // four rows per thread and iteration, all loads issued before the first use (r03: one dependent 16-byte load per thread and
+    // iteration kept ~32 KB in flight per CU: 3.7 TB/s; rows past the end re-read the first row and are not stored)
+    for (long long r = r_begin + rsub; r < r_end; r += 4 * rpp) {
+        f32x4 v[4], q[4];
+        bool ok[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float y = (v[i] - mu[i]) * ga[i] + be[i];
-            if (scale_shift) y = y * sc[i] + sh[i];
-            v[i] = y / (1.0f + expf(-y));
+        for (int u = 0; u < 4; ++u) {
+            const long long ru = r + (long long)u * rpp;
+            ok[u] = ru < r_end;
+            const long long o = (ok[u] ? ru : r) * C + c4 * 4;
+            v[u] = *reinterpret_cast<const f32x4*>(xb + o);
+            if (rb) q[u] = *reinterpret_cast<const f32x4*>(rb + o);
         }
-        if (rb) v += *reinterpret_cast<const f32x4*>(rb + r * C + c4 * 4);
-        omx = max(omx, max(max(abs_bits(v[0]), abs_bits(v[1])), max(abs_bits(v[2]), abs_bits(v[3]))));
-        *reinterpret_cast<f32x4*>(ob + r * C + c4 * 4) = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y = (v[u][i] - mu[i]) * ga[i] + be[i];
+                if (scale_shift) y = y * sc[i] + sh[i];
+                v[u][i] = y / (1.0f + expf(-y));
+            }
+            if (rb) v[u] += q[u];
+            if (ok[u]) {
+                omx = max(omx, max(max(abs_bits(v[u][0]), abs_bits(v[u][1])), max(abs_bits(v[u][2]), abs_bits(v[u][3]))));
+                *reinterpret_cast<f32x4*>(ob + (r + (long long)u * rpp) * C + c4 * 4) = v[u];
+            }
+        }
     }
     if (oflag && omx > F16X3_ACT_LIMIT_BITS) atomicOr(oflag, 1);     // f16x3 activation-range sentinel (common.h)
 }
