@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256) void small_linear_multi_kernel(const float* __
     }
 }
 
+// in_act applied once: the multi kernel evaluated SiLU(in[b][k]) again for every output column (N_total x B x K expf: 1.2 ms of the
+// Burgers step at B = 256, r03 trace); the activated input goes to a scratch buffer first, the products see the same floats
+__global__ __launch_bounds__(256) void small_act_kernel(const float* __restrict__ in, float* __restrict__ out, long long n, int act) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = act_apply(in[i], act);
+}
+
 int launch_small_linear_multi(const float* in, const SmallLinearBatch& d, int B, int K, int in_act, int out_act, hipStream_t s) {
     if (B == 0 || d.count == 0) return DPC_OK;
     DPC_REQUIRE(d.count <= 32 && K <= 1024, "small_linear_multi: at most 32 sets, K <= 1024");
@@ -99,6 +106,25 @@ int launch_small_linear_multi(const float* in, const SmallLinearBatch& d, int B,
     double nsum = 0;
     for (int i = 0; i < d.count; ++i) { nmax = std::max(nmax, d.N[i]); nsum += d.N[i]; }
     ProfScope prof(PROF_SMALL, 2.0 * B * nsum * K, 4.0 * (nsum * K + (double)B * (nsum + K)), s);
+    if (in_act != 0) {
+        // per-device scratch, grown geometrically and never freed (a captured HIP graph may hold the pointer)
+        static float* scratch[64] = {};
+        static size_t cap[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        const size_t need = (size_t)B * K * sizeof(float);
+        if (need > cap[dev]) {
+            const size_t want = std::max(need, 2 * cap[dev]);
+            DPC_HIP(hipMalloc(&scratch[dev], want));
+            cap[dev] = want;
+        }
+        const long long n = (long long)B * K;
+        hipLaunchKernelGGL(small_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, scratch[dev], n, in_act);
+        DPC_LAUNCH_CHECK();
+        in = scratch[dev];
+        in_act = 0;
+    }
     const int bb = B >= 64 ? 16 : 1;
     const int nbb = (B + bb - 1) / bb;
     const dim3 grid((unsigned)(((long long)nbb * nmax + 3) / 4), (unsigned)d.count), blk(256);
