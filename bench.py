@@ -25,6 +25,7 @@ The JSON line also carries
 """
 import argparse
 import json
+import contextlib
 import os
 import socket
 import subprocess
@@ -495,7 +496,8 @@ def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
                                   results_path=a.inference_result_path, args_general=a)
         ctx.sync()
         t0 = time.perf_counter()
-        ppl.run(J.synthetic_batches(a))
+        with contextlib.redirect_stdout(sys.stderr):      # the entry script prints its results: stdout carries the ONE JSON line only
+            ppl.run(J.synthetic_batches(a))
         ctx.sync()
         times[T] = time.perf_counter() - t0
         del ppl, diffusion, force_model, bd_updater, design_fn
