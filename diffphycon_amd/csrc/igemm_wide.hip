@@ -14,8 +14,11 @@
 // (3 us per chunk, 26 % of the MFMA-bound rate).  Now: no branch in the loop body (out-of-image rows load row 0 and are zeroed
 // at the split; iterations past the end re-load the last chunk), the per-row (frame, y, x) decomposition is done once, and the
 // tap offsets come from an LDS table (lgkmcnt, not vmcnt).
-// Same arithmetic, operand scales, partial-product order, split-K protocol and epilogues as igemm3_kernel; the reduction is walked
-// in the same (tap, chunk) order, so the sums are bit-identical to the narrow kernel's.
+// Same arithmetic, operand scales, partial-product order and epilogues as igemm3_kernel, and the reduction is walked in the same
+// (tap, chunk) order.  NOT claimed bit-identical to the narrow kernel: the split-K slicing differs (by N here, by reduction length
+// there), so launches that split sum their slices in a different grouping (tools/bench_igemm.py: 2.4e-6 vs 2.1e-6 of the output
+// range against x6 on the 512 -> 256 concat shape).  What IS guaranteed and tested is that a result never depends on the batch:
+// tile shape, slice count and kernel choice are functions of (N, taps, K) only.
 #include <algorithm>
 
 #include "common.h"
