@@ -664,9 +664,11 @@ def main():
     s128 = args.workload == "s128"
     frames, size = (64, 128) if s128 else (FRAMES, SIZE)
     B = args.batch or (8 if s128 else LOCAL_BATCH)
-    # micro-batch 16: 4 forwards per net and step; the persistent conv kernel then walks 32 tiles per workgroup on the largest layers
-    # (8: 289.3 ms per step, 16: 286.1, 4: 311.1 on one box); the activation workspace is ~10 GB
-    mbatch = args.micro_batch or (1 if s128 else 16)
+    # micro-batch 32: 2 forwards per net and step; the persistent conv kernel then walks 64 tiles per workgroup on the largest layers
+    # (r02, one box: 4: 311.1 ms per step, 8: 289.3, 16: 286.1; r03, one box, interleaved: 16: 282.9 / 284.2, 32: 279.4 / 280.0,
+    # 64: 279.1); the activation workspace is ~20 GB of the 288; outputs are bit-identical for every micro-batch
+    # (tests/test_gpu_unet3d.py: test_unet3d_bench_micro_batches_are_bit_identical, B = 32 at micro-batch 4 / 16 / 32)
+    mbatch = args.micro_batch or (1 if s128 else 32)
     unit_gflop = 14534.0 if s128 else UNIT_GFLOP
     gd, sd_cpu = build_models(device, mbatch, frames=frames, size=size)
     guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
