@@ -454,9 +454,9 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
 
 
 def run_s128_leg(ctx, args, t_start, batch=8):
-    """BASELINE.json configs[4] shape (S128: 128 x 128 x 64 frames), batch 8 per GPU, micro-batch 1: the headline step at that extent."""
+    """BASELINE.json configs[4] shape (S128: 128 x 128 x 64 frames), batch 8 per GPU, micro-batch 4: the headline step at that extent."""
     from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
-    gd, _ = build_models(ctx.device, 1, frames=64, size=128)
+    gd, _ = build_models(ctx.device, 4, frames=64, size=128)      # micro-batch 4 (1: 361 ms per step, 2: 326, 4: 308)
     guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
     gd.noise_seed, gd.traj_offset = 0, ctx.rank * batch
     init = torch.nn.functional.interpolate(synthetic_init(batch, ctx.rank * batch)[:, None], scale_factor=2)[:, 0].to(ctx.device)
@@ -472,7 +472,7 @@ def run_s128_leg(ctx, args, t_start, batch=8):
     ctx.log(t_start, f"s128: {sec * 1e3:.1f} ms/step")
     return {"metric": "guided trajectories/sec, 2D smoke 128x128x64 @1000 DDPM steps", "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec),
             "unit": "trajectories/s", "n_gpus": ctx.world, "steps": args.steps, "ms_per_step": sec * 1e3, "dtype": "f32",
-            "config": {"workload": f"S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU, micro-batch 1",
+            "config": {"workload": f"S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU, micro-batch 4",
                        "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
 
 
@@ -668,7 +668,7 @@ def main():
     # (r02, one box: 4: 311.1 ms per step, 8: 289.3, 16: 286.1; r03, one box, interleaved: 16: 282.9 / 284.2, 32: 279.4 / 280.0,
     # 64: 279.1); the activation workspace is ~20 GB of the 288; outputs are bit-identical for every micro-batch
     # (tests/test_gpu_unet3d.py: test_unet3d_bench_micro_batches_are_bit_identical, B = 32 at micro-batch 4 / 16 / 32)
-    mbatch = args.micro_batch or (1 if s128 else 32)
+    mbatch = args.micro_batch or (4 if s128 else 32)      # (s128, r03 one box, interleaved: 1: 361.1 ms per step, 2: 326.3, 4: 308.4)
     unit_gflop = 14534.0 if s128 else UNIT_GFLOP
     gd, sd_cpu = build_models(device, mbatch, frames=frames, size=size)
     guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
