@@ -378,28 +378,31 @@ def test_unet3d_full_size_micro_batch_invariance(dev):
     assert torch.equal(m(x[perm], t[perm]), outs[0][perm])
 
 
+@pytest.mark.parametrize("B,mbs", [(32, (4, 16, 32)), (64, (8, 0))], ids=["B32-mb4-16-32", "B64-mb8-whole"])
 @pytest.mark.parametrize("channels", [6, 2], ids=["joint", "prior"])
-def test_unet3d_bench_micro_batches_are_bit_identical(channels, dev):
-    """The micro-batches bench.py actually runs (32 since r03, 16 before) against a small one, S64 extent, B = 32: at micro-batch 32
-    the largest activation (128 concat channels at 64 x 64) is 2.1 GB -- past 2^31 bytes, which no smaller case reaches -- so a
-    32-bit byte offset anywhere in a kernel would show up here and nowhere else.  Trajectories are independent: torch.equal."""
+def test_unet3d_bench_micro_batches_are_bit_identical(channels, B, mbs, dev):
+    """The micro-batches that actually run at S64 extent against a small one: bench.py's 32 (since r03; 16 before), and the entry
+    script's default -- micro_batch = 0 = the whole batch in one forward (inference/inference_2d_smoke.py builds the nets without
+    the argument) -- at B = 64.  At micro-batch 32 the largest activation (128 concat channels at 64 x 64) is 2.1 GB, at 64 it is
+    4.3 GB: past 2^31 and 2^32 bytes, which no smaller case reaches, so a 32-bit byte offset anywhere in a kernel would show up
+    here and nowhere else.  Trajectories are independent: torch.equal."""
     from oracle import unet3d as O
     from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=channels)
     sd = O.synthetic_state_dict(cfg, seed=13)
     gen = torch.Generator().manual_seed(13)
-    x = torch.randn(32, 32, channels, 64, 64, generator=gen).to(dev)
-    t = torch.randint(0, 1000, (32,), generator=gen).to(dev)
-    outs = {}
-    for mb in (4, 16, 32):
+    x = torch.randn(B, 32, channels, 64, 64, generator=gen).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=gen).to(dev)
+    outs = []
+    for mb in mbs:
         m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=channels, micro_batch=mb)
         m.load_state_dict(sd)
-        outs[mb] = m.to(dev)(x, t).clone()
+        outs.append(m.to(dev)(x, t).clone())
         del m
         torch.cuda.empty_cache()
-    assert torch.isfinite(outs[4]).all()
-    assert torch.equal(outs[4], outs[16]), "micro-batch 16 differs from micro-batch 4"
-    assert torch.equal(outs[4], outs[32]), "micro-batch 32 differs from micro-batch 4"
+    assert torch.isfinite(outs[0]).all()
+    for mb, o in zip(mbs[1:], outs[1:]):
+        assert torch.equal(outs[0], o), f"micro-batch {mb} differs from micro-batch {mbs[0]}"
 
 
 def test_weight_outside_the_f16x3_range_fails_loudly(dev):
