@@ -179,19 +179,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* out, const float* resid,
-                                                       const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ scale_shift, long long R, int C,
-                                                       int groups, int nblk, int* oflag) {
-    __shared__ float s_mean[1024], s_rstd[1024];   // per group (groups <= 1024)
-    const int b = blockIdx.y, tid = threadIdx.x;
+// rows [r_begin, r_end) of sample b: out = SiLU((x - mean_g) * rstd_g * gamma + beta) * (scale + 1) + shift) (+ resid); shared by the
+// streaming apply kernel and the one-pass kernel below (identical per-element arithmetic)
+__device__ __forceinline__ void gn_apply_rows(const float* x, float* out, const float* resid, const float* s_mean, const float* s_rstd,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              const float* __restrict__ scale_shift, long long R, int C, int groups, int b,
+                                              long long r_begin, long long r_end, int* oflag) {
+    const int tid = threadIdx.x;
     const int cpg = C / groups;
-    for (int g = tid; g < groups; g += 256) {
-        s_mean[g] = stats[2 * (b * groups + g)];
-        s_rstd[g] = stats[2 * (b * groups + g) + 1];
-    }
-    __syncthreads();
     const int tpr = C >> 2, rpp = 256 / tpr;
     const int c4 = tid % tpr, rsub = tid / tpr;
     float mu[4], ga[4], be[4], sc[4], sh[4];
@@ -207,11 +202,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
     const float* xb = x + (long long)b * R * C;
     float* ob = out + (long long)b * R * C;
     const float* rb = resid ? resid + (long long)b * R * C : nullptr;
-    const long long rpb = (R + nblk - 1) / nblk;
-    const long long r_begin = blockIdx.x * rpb, r_end = min(R, r_begin + rpb);
     unsigned omx = 0;
-    // four rows per thread and iteration, all loads issued before the first use (r03: one dependent 16-byte load per thread and
-    // iteration kept ~32 KB in flight per CU: 3.7 TB/s; rows past the end re-read the first row and are not stored)
+    // four rows per thread and iteration, all loads issued before the first use (rows past the end re-read the first row and are
+    // not stored); r03: no gain on the 64 x 64 level -- x + residual + out already move at 5.6 TB/s
     for (long long r = r_begin + rsub; r < r_end; r += 4 * rpp) {
         f32x4 v[4], q[4];
         bool ok[4];
@@ -239,6 +232,91 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* ou
         }
     }
     if (oflag && omx > F16X3_ACT_LIMIT_BITS) atomicOr(oflag, 1);     // f16x3 activation-range sentinel (common.h)
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, float* out, const float* resid,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ scale_shift, long long R, int C,
+                                                       int groups, int nblk, int* oflag) {
+    __shared__ float s_mean[1024], s_rstd[1024];   // per group (groups <= 1024)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int g = tid; g < groups; g += 256) {
+        s_mean[g] = stats[2 * (b * groups + g)];
+        s_rstd[g] = stats[2 * (b * groups + g) + 1];
+    }
+    __syncthreads();
+    const long long rpb = (R + nblk - 1) / nblk;
+    const long long r_begin = blockIdx.x * rpb, r_end = min(R, r_begin + rpb);
+    gn_apply_rows(x, out, resid, s_mean, s_rstd, gamma, beta, scale_shift, R, C, groups, b, r_begin, r_end, oflag);
+}
+
+// One launch per GroupNorm for samples whose statistics take ONE row chunk (gn_chunks == 1: the 4 x 32, 2 x 16, 1 x 8 levels of the
+// Burgers U-Net -- 64 of its 84 GroupNorms per step ran as three launches of 8 + 5 + 13-18 us each).  One workgroup per sample does
+// what gn_partial_kernel (one chunk), gn_finalize_kernel and gn_apply_kernel do, with the SAME thread mapping, fp32 row sums, fp64
+// folds and butterfly order: the statistics and the outputs are bit-identical to the three-launch path (checked A/B: DPC_GN_ONEPASS=0).
+// The second read of x comes from L2 (<= 128 KB per sample).
+__global__ __launch_bounds__(256) void gn_onepass_kernel(const float* x, float* out, const float* resid,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ scale_shift, long long R, int C, int groups,
+                                                         int* oflag) {
+    __shared__ double red[256][8];
+    __shared__ double chs[1024][2];                // per channel (sum, sum of squares)
+    __shared__ float s_mean[1024], s_rstd[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tpr = C >> 2, rpp = 256 / tpr;
+    const int c4 = tid % tpr, rsub = tid / tpr;
+    const float* xb = x + (long long)b * R * C;
+    {   // gn_partial_kernel, chunk 0 of 1
+        f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+        for (long long r = rsub; r < R; r += rpp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
+            s += v;
+            q += v * v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[tid][i] = (double)s[i];
+            red[tid][4 + i] = (double)q[i];
+        }
+        __syncthreads();
+        if (tid < tpr) {
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < rpp; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += red[tid + k * tpr][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                chs[tid * 4 + i][0] = acc[i];
+                chs[tid * 4 + i][1] = acc[4 + i];
+            }
+        }
+        __syncthreads();
+    }
+    {   // gn_finalize_kernel: one wave per group, lane-strided fp64 sums + xor butterfly
+        const int cpg = C / groups;
+        for (int g = wave; g < groups; g += 4) {
+            double s = 0, q = 0;
+            for (int i = lane; i < cpg; i += 64) {
+                s += chs[g * cpg + i][0];
+                q += chs[g * cpg + i][1];
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (lane == 0) {
+                const double n = (double)R * cpg;
+                const double mean = s / n;
+                double var = q / n - mean * mean;
+                if (var < 0) var = 0;
+                s_mean[g] = (float)mean;
+                s_rstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+            }
+        }
+        __syncthreads();
+    }
+    gn_apply_rows(x, out, resid, s_mean, s_rstd, gamma, beta, scale_shift, R, C, groups, b, 0, R, oflag);
 }
 
 // ---- fused-statistics path: the conv3x6 epilogue already produced per-tile channel sums (Conv3hParams::gn_part)
@@ -346,6 +424,13 @@ int launch_groupnorm_silu(const float* x, float* out, const float* resid, const 
     if (B == 0 || R == 0) return DPC_OK;
     const int nchunk = gn_chunks(R, C);
     ProfScope prof(PROF_GN, 0, 4.0 * (double)B * R * C * (resid ? 4 : 3), s);
+    static const int onepass = debug_switch("DPC_GN_ONEPASS", 1);
+    if (onepass && nchunk == 1 && out != nullptr) {       // shape-only rule; bit-identical to the three launches below either way
+        hipLaunchKernelGGL(gn_onepass_kernel, dim3(B), dim3(256), 0, s, x, out, resid, gamma, beta, scale_shift, R, C, groups,
+                           overflow_flag_current());
+        DPC_LAUNCH_CHECK();
+        return DPC_OK;
+    }
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, part, R, C, nchunk);
     DPC_LAUNCH_CHECK();
