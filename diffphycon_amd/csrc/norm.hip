@@ -269,10 +269,19 @@ __global__ __launch_bounds__(256) void gn_onepass_kernel(const float* x, float* 
     const float* xb = x + (long long)b * R * C;
     {   // gn_partial_kernel, chunk 0 of 1
         f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-        for (long long r = rsub; r < R; r += rpp) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + r * C + c4 * 4);
-            s += v;
-            q += v * v;
+        for (long long r = rsub; r < R; r += 4 * rpp) {           // four loads in flight, accumulated in row order (same sums)
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long ru = r + (long long)u * rpp;
+                v[u] = *reinterpret_cast<const f32x4*>(xb + (ru < R ? ru : r) * C + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + (long long)u * rpp < R) {
+                    s += v[u];
+                    q += v[u] * v[u];
+                }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
