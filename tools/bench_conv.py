@@ -12,17 +12,18 @@ sys.path.insert(0, ROOT)
 from diffphycon_amd import _lib  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+MB = int(sys.argv[2]) if len(sys.argv) > 2 else 8          # micro-batch (bench.py runs 32 since r03)
 dev = torch.device("cuda:0")
 L = _lib.lib()
 SHAPES = [  # B, F, H, W, Cin, Cout   (count per U-Net forward in parentheses)
-    (8, 32, 64, 64, 64, 64),      # level 0 blocks (x7)
-    (8, 32, 64, 64, 128, 64),     # ups level 0 block1 with concat / final (x2)
-    (8, 32, 32, 32, 64, 128),     # level 1 first block
-    (8, 32, 32, 32, 128, 128),    # level 1 (x5)
-    (8, 32, 32, 32, 256, 128),    # ups level 1 concat
-    (8, 32, 16, 16, 128, 256),    # level 2 first
-    (8, 32, 16, 16, 256, 256),    # level 2 / mid (x7)
-    (8, 32, 16, 16, 512, 256),    # ups level 2 concat
+    (MB, 32, 64, 64, 64, 64),      # level 0 blocks (x7)
+    (MB, 32, 64, 64, 128, 64),     # ups level 0 block1 with concat / final (x2)
+    (MB, 32, 32, 32, 64, 128),     # level 1 first block
+    (MB, 32, 32, 32, 128, 128),    # level 1 (x5)
+    (MB, 32, 32, 32, 256, 128),    # ups level 1 concat
+    (MB, 32, 16, 16, 128, 256),    # level 2 first
+    (MB, 32, 16, 16, 256, 256),    # level 2 / mid (x7)
+    (MB, 32, 16, 16, 512, 256),    # ups level 2 concat
 ]
 tot = 0.0
 for (B, Fr, H, W, Ci, Co) in SHAPES:
