@@ -196,6 +196,9 @@ int launch_igemm6(const IgemmParams& p, const void* wp6, hipStream_t s);
 // launch_igemm6 (nsl > 1: split-K slices, raw partials into p.part)
 // 64-row x all-N panels for 1-tap ops with K <= 256 (igemm_panel.hip); p as prepared by launch_igemm6
 bool igemm3p_supported(const IgemmParams& p);
+// pixel tiles for the stride-1 2 x 2-tap classes of ConvTranspose (igemm_tile.hip)
+bool igemm3t_supported(const IgemmParams& p);
+int launch_igemm3t(const IgemmParams& p, const void* wp6, hipStream_t s);
 int launch_igemm3p(const IgemmParams& p, const void* wp6, hipStream_t s);
 bool igemm3w_supported(const IgemmParams& p);
 int igemm3w_slices(const IgemmParams& p);      // split-K slices by shape (N, reduction length), never by the batch

@@ -560,6 +560,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
     ProfScope prof((p.Npad % 128 == 0 && p.N > 64) ? PROF_IGEMM128 : PROF_IGEMM64, flops, bytes, s);
     if (igemm_mode_default() == 2) {
         const size_t lds3 = 2 * (size_t)g3::BM * g3::RS;
+        if (igemm3t_supported(p)) return launch_igemm3t(p, wp6, s);      // stride-1 2 x 2-tap classes: unique pixels staged once (igemm_tile.hip)
         if (igemm3p_supported(p)) return launch_igemm3p(p, wp6, s);      // 1-tap, K <= 256: 64-row panels over all N (igemm_panel.hip)
         // split-K for the GEMM-shaped deep levels of the 2-D U-Net (K x taps >= 4096: few row tiles, hundreds of iterations;
         // 256 workgroups leave three quarters of the 4-per-CU slots empty): four slices of the iteration range run as

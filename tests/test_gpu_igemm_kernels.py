@@ -2,7 +2,9 @@
 restatement of the operator, on shapes chosen to land in each kernel and each of its edge paths:
 
   * row panels (csrc/igemm_panel.hip): 1-tap K <= 512, N in {64, 128, 256, 384}; LayerNorm prologue, residual, virtual concat,
-    K % 32 != 0 falls back; few-tap im2col form incl. the ConvTranspose parity scatter (out_mode 2) and the 32-row / 16-chunk form;
+    K % 32 != 0 falls back; few-tap im2col form (stride-2 pixel-unshuffle conv);
+  * pixel tiles (csrc/igemm_tile.hip): the stride-1 2 x 2-tap classes of ConvTranspose at 64 -> 64 and 128 -> 128 channels, plain
+    and with the parity scatter (out_mode 2), every parity's tap offsets, images narrower than a tile;
   * LDS-tiled wide kernel (csrc/igemm_wide.hip): reductions of >= 24 chunks, 128- and 64-column tiles, split-K by N, K % 32 != 0;
   * the narrow kernel (csrc/igemm6.hip) for what neither takes (shared vector epilogue, fragment-order weight pack).
 
@@ -70,6 +72,8 @@ CASES = [
     ("taps 2x2 64->64", 3, 5, 7, 64, 0, 64, (2, 2), (1, 1), (0, 0), False, False, None),
     ("taps 2x2 64->64 parity (1,0)", 3, 5, 7, 64, 0, 64, (2, 2), (1, 1), (1, 0), False, False, (1, 0)),
     ("taps 2x2 64->64 parity (0,1)", 3, 6, 5, 64, 0, 64, (2, 2), (1, 1), (0, 1), False, False, (0, 1)),
+    ("taps 2x2 64->64 parity (0,0), 40 x 33 images (tile inside a row, across rows and images)", 2, 40, 33, 64, 0, 64, (2, 2), (1, 1), (0, 0), False, False, (0, 0)),
+    ("taps 2x2 concat 64+64->128 parity (1,0)", 3, 9, 11, 64, 64, 128, (2, 2), (1, 1), (1, 0), False, False, (1, 0)),
     ("taps 2x2 128->128 parity (1,1) 32-row", 3, 5, 7, 128, 0, 128, (2, 2), (1, 1), (1, 1), False, False, (1, 1)),
     ("taps 2x2 s2 64->128 (pixel-unshuffle conv)", 3, 6, 10, 64, 0, 128, (2, 2), (2, 2), (0, 0), False, False, None),
     # ---- neither: K % 32 != 0 and N = 192 stay on the narrow kernel (shared epilogue, fragment-order pack)
@@ -118,7 +122,7 @@ def run_case(SH, dev, case, mode, images_used=None):
         got = out.reshape(n_img, Ho, Wo, N)
     else:
         out = torch.full((n_img * 4 * Ho * Wo, N), float("nan"), device=dev)
-        conv(a0, n_img, H, W, bias=bias.to(dev), out=out, Ho=Ho, Wo=Wo, out_mode=2, par=par)
+        conv(a0, n_img, H, W, a1=a1, bias=bias.to(dev), out=out, Ho=Ho, Wo=Wo, out_mode=2, par=par)
         full = out.reshape(n_img, 2 * Ho, 2 * Wo, N)
         got = full[:, par[0]::2, par[1]::2]
         rest = full.clone()

@@ -1,0 +1,33 @@
+"""Repeat the Burgers two-rank-vs-one-rank entry-script comparison of tests/test_gpu_inference_scripts.py N times and print every
+J_actual / Energy value (flake hunting: one full-suite run of r03 saw the two-rank result differ once).
+  gpurun -- 'python tools/rank_stress.py [repeats] [graph 0/1]'
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_inference_scripts as T
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if len(sys.argv) > 2:
+    os.environ["DPC_BURGERS_GRAPH"] = sys.argv[2]
+args = ["inference/inference_1d_burgers.py", "--dataset", "free_u_f_1e5_front_rear_quarter", "--partial_control",
+        "front_rear_quarter", "--partially_observed", "front_rear_quarter", "--train_on_partially_observed", "None",
+        "--set_unobserved_to_zero_during_sampling", "True", "--is_condition_u0", "True", "--is_condition_uT", "True",
+        "--J_scheduler", "cosine", "--dim", "16", "--dim_muls", "1", "2", "4", "--exp_id", "POPC",
+        "--dim__model_w", "16", "--dim_muls__model_w", "1", "2", "--exp_id__model_w", "POPC_w",
+        "--is_model_w", "False", "--eval_two_models", "True", "--prior_beta", "0.9", "--w_scheduler", "sigmoid_flip",
+        "--wus", "0.5", "--synthetic", "True", "--n_test_samples", "3", "--batch_size", "3", "--timesteps_override", "6"]
+vals = lambda out: tuple(repr(T._floats_after(out, k)) for k in ("J_actual:", "Energy:"))
+ref = vals(T.run(args, ROOT))
+print("one rank ", ref, flush=True)
+bad = 0
+for i in range(n):
+    one = vals(T.run(args, ROOT))
+    two = vals(T.run_ranks(2, args, ROOT))
+    if one != ref or two[0].count(eval(ref[0])[-1].__repr__()) == 0:
+        pass
+    ok1 = one == ref
+    ok2 = all(x == eval(ref[0])[-1] for x in eval(two[0])) and all(x == eval(ref[1])[-1] for x in eval(two[1]))
+    bad += (not ok1) + (not ok2)
+    print(i, "one-rank repeat", "same" if ok1 else one, "| two ranks", "same" if ok2 else two, flush=True)
+print("mismatches", bad)
