@@ -223,6 +223,140 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
     }
 }
 
+// ---- channel-pair form (r03, f16x3 only; default).  The slot forms above pad a tap row's (dw, c) run to whole 16-byte point slots:
+// 42 of 64 k-values useful at C = 6 (14 of 32 for the prior denoiser's C = 2 with 4-channel slots) -- a third to a half of the
+// MFMAs multiply zeros, and the kernel is matrix-bound.  Here the halo is stored per CHANNEL PAIR: plane (cp, split plane) holds
+// 100 rows of 4-byte points (2 fp16 channels), and one MFMA k-step is  k = (dw 0..7, c in the pair)  = 16 contiguous bytes starting
+// at point lw + 4 hh of the tap's row: 14 of 16 k-values useful for every even C (the 8th w-tap carries zero weights), ceil(C / 2)
+// k-steps per tap row -- 3 instead of 4 at C = 6, 1 instead of 2 at C = 2.  The fragments are only 4-byte aligned (point pitch 4 B),
+// so they are read as four dwords; rows are 24 dwords apart: the four rows of a 32-lane pass start at banks 0 / 24 / 16 / 8 and each
+// touches 8 consecutive dwords -- conflict-free without rotation (same-address lanes broadcast).
+namespace s7p {
+constexpr int ROWB = 96;                                   // 24 dwords: 15 points addressed (w + 7 <= 14), the rest padding
+constexpr int PLANEB = s7::HF * s7::HH * ROWB;             // 9 600 B per (channel pair, split plane)
+}
+
+template <int NCP>
+__global__ __launch_bounds__(256, 2) void stem7p_kernel(StemParams p, const unsigned char* __restrict__ wp6) {
+    using namespace s7;
+    constexpr int ROWB = s7p::ROWB, PLANEB = s7p::PLANEB;
+    constexpr int WROWB = 64;                                     // packed weight bytes per (step, n): 2 planes x 16 fp16
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+    unsigned char* halo = smem7;                                  // [NCP][2 planes][HF][HH][24 dwords]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hh = lane >> 5;
+    const int ntn = p.Npad / 64;
+    const int ntf = (p.F + TF - 1) / TF, nth = (p.H + TH - 1) / TH, ntw = (p.W + TW - 1) / TW;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int n0 = (bid % ntn) * 64;
+    int t = bid / ntn;
+    const int w0 = (t % ntw) * TW; t /= ntw;
+    const int h0 = (t % nth) * TH; t /= nth;
+    const int f0 = (t % ntf) * TF;
+    const int b = t / ntf;
+    const long long HWin = (long long)p.H * p.W;
+
+    // ---- stage the halo: one thread per point (16 per row: points 14, 15, out-of-range points and channels >= C are zero).
+    // (Issuing all 7 rounds of loads before the first conversion, with unconditional loads, was measured SLOWER: 4.05 vs 3.69 ms at
+    // C = 6 -- the second workgroup of the CU already hides this phase.)
+    for (int q = tid; q < NPT; q += 256) {
+        const int slot = q % SLOTS, row = q / SLOTS;              // row = pf * HH + ph
+        const int pf = row / HH, ph = row % HH;
+        const int f = f0 - 3 + pf, h = h0 - 3 + ph, w = w0 - 3 + slot;
+        float v[2 * NCP];
+#pragma unroll
+        for (int c = 0; c < 2 * NCP; ++c) v[c] = 0.f;
+        if (slot < HWL && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) {
+            const float* src = p.x + (((long long)b * p.F + f) * p.Ctot + p.c_off) * HWin + (long long)h * p.W + w;
+#pragma unroll
+            for (int c = 0; c < 2 * NCP; ++c)
+                if (c < p.C) v[c] = src[(long long)c * HWin];
+        }
+        unsigned char* dst = halo + row * ROWB + slot * 4;
+#pragma unroll
+        for (int cp = 0; cp < NCP; ++cp) {
+            unsigned a1, a2;
+            split2_2(v[2 * cp] * SA, v[2 * cp + 1] * SA, a1, a2);
+            *reinterpret_cast<unsigned*>(dst + (2 * cp) * PLANEB) = a1;
+            *reinterpret_cast<unsigned*>(dst + (2 * cp + 1) * PLANEB) = a2;
+        }
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    int lh, lw;
+    lane_hw(l31, lh, lw);
+    // weight fragments: [(df*7+dh) * NCP + cp][Npad][2 planes][16] fp16, k = dw * 2 + (c & 1)
+    const unsigned char* wlane = wp6 + ((long long)n0 + wn * 32 + l31) * WROWB + hh * 16;
+    const long long wstep = (long long)p.Npad * WROWB;
+    f16x8_s wc[2], wx[2];
+    auto ldw = [&](int step, f16x8_s (&w)[2]) {
+        const unsigned char* src = wlane + (long long)step * wstep;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) w[pl] = *reinterpret_cast<const f16x8_s*>(src + pl * 32);
+    };
+    ldw(0, wc);
+    __syncthreads();
+
+    const int abase = (wm * 2 * HH + lh) * ROWB + (lw + 4 * hh) * 4;      // frame wm*2 (+ mt + df), halo row lh (+ dh), point lw + 4 hh
+    for (int df = 0; df < 7; ++df) {
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh) {
+            const unsigned char* arow = halo + abase + (df * HH + dh) * ROWB;
+#pragma unroll
+            for (int cp = 0; cp < NCP; ++cp) {
+                const int step = (df * 7 + dh) * NCP + cp;
+                if (step + 1 < 49 * NCP) ldw(step + 1, wx);
+                f16x8_s a[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const unsigned* src = reinterpret_cast<const unsigned*>(arow + (2 * cp + pl) * PLANEB + mt * (HH * ROWB));
+                        a[mt][pl] = __builtin_bit_cast(f16x8_s, u32x4{src[0], src[1], src[2], src[3]});
+                    }
+                constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};                       // small terms first
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wc[pl] = wx[pl];
+            }
+        }
+    }
+
+    const int n = n0 + wn * 32 + l31;
+    if (n < p.N) {
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int f = f0 + wm * 2 + mt;
+            if (f >= p.F) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                int ih, iw;
+                lane_hw(i, ih, iw);
+                const int h = h0 + ih, w = w0 + iw;
+                if (h < p.H && w < p.W)
+                    p.out[((((long long)b * p.F + f) * p.H + h) * p.W + w) * p.N + n] = acc[mt][r] * DESCALE + bv;
+            }
+        }
+    }
+}
+
+
 bool stem7x6_supported(int C, int k) { return k == 7 && C >= 1 && C <= 8; }
 size_t stem7x6_packed_bytes(int Npad) { return (size_t)196 * Npad * 96; }      // sized for 3 planes; f16x3 uses 64 of the 96 B
 
@@ -231,6 +365,28 @@ static bool stem_h3() { return modes_current().stem != 1; }
 static bool stem_cs4(int C) {
     static const int ok = debug_switch("DPC_STEM_CS4", 1);
     return ok && C <= 4 && stem_h3();
+}
+
+// channel-pair form (stem7p_kernel) for the f16x3 arithmetic; DPC_STEM_PAIRS=0 keeps the slot forms (A/B)
+// It is taken where it saves k-steps -- C <= 2 (1 instead of 2 per tap row) and C = 5, 6 (3 instead of 4); at equal MFMA counts
+// (C = 3, 4, 7, 8) the slot forms' aligned 16-byte fragment reads are ~3 % faster (tools/bench_stem.py).  Returns the pair count or 0.
+static int stem_ncp(int C) {
+    static const int ok = debug_switch("DPC_STEM_PAIRS", 1);
+    const int n = (C + 1) / 2;
+    return (ok && stem_h3() && (n == 1 || n == 3)) ? n : 0;
+}
+
+template <int NCP>
+static int launch_p7(const StemParams& p, const void* wp6, unsigned grid, hipStream_t s) {
+    constexpr int LDS = 2 * NCP * s7p::PLANEB;
+    static DeviceOnce once;
+    if (!once) {
+        DPC_HIP(hipFuncSetAttribute((const void*)stem7p_kernel<NCP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        once = true;
+    }
+    hipLaunchKernelGGL(stem7p_kernel<NCP>, dim3(grid), dim3(256), LDS, s, p, (const unsigned char*)wp6);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
 }
 
 int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
@@ -245,6 +401,7 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
     const bool h3 = stem_h3(), cs4 = stem_cs4(p.C);
     const size_t lds = cs4 ? (size_t)PLANEB : (h3 ? 2 : 3) * (size_t)PLANEB;       // (4-channel slots: 2 planes of half the size)
     ProfScope prof(PROF_STEM, 2.0 * (double)p.M * p.N * 343.0 * p.C, 4.0 * ((double)p.M * p.N + (double)p.M * p.C), s);
+    if (const int ncp = stem_ncp(p.C)) return ncp == 1 ? launch_p7<1>(p, wp6, (unsigned)grid, s) : launch_p7<3>(p, wp6, (unsigned)grid, s);
     static DeviceOnce once;
     if (!once) {
         DPC_HIP(hipFuncSetAttribute((const void*)stem7x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PLANEB));
@@ -260,16 +417,19 @@ int launch_stem7x6(const StemParams& p, const void* wp6, hipStream_t s) {
 
 // reference weight [N][C][7][7][7] fp32 -> [(df*7+dh)*4 + ks][Npad][3 planes][16] bf16, k = (dw - 2 ks) * 8 + c
 // (cs4: [(df*7+dh)*2 + ks][Npad][2 planes][16] fp16, k = (dw - 4 ks) * 4 + c)
+// (pairs: [(df*7+dh) * ncp + cp][Npad][2 planes][16] fp16, k = dw * 2 + (c - 2 cp); ncp = ceil(C / 2) k-steps per tap row)
 __global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int C, int h3, int cs4,
-                                    int* __restrict__ ovf) {
-    const long long total = (cs4 ? 98ll : 196ll) * Npad * 16;
+                                    int ncp, int* __restrict__ ovf) {
+    const long long total = (ncp ? 49ll * ncp : cs4 ? 98ll : 196ll) * Npad * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(i % 16);
         long long r = i / 16;
         const int n = (int)(r % Npad);
         const int step = (int)(r / Npad);
-        const int ks = cs4 ? (step & 1) : (step & 3), tap = cs4 ? (step >> 1) : (step >> 2), df = tap / 7, dh = tap % 7;
-        const int dw = cs4 ? 4 * ks + (kk >> 2) : 2 * ks + (kk >> 3), c = cs4 ? (kk & 3) : (kk & 7);
+        const int ks = ncp ? step % ncp : cs4 ? (step & 1) : (step & 3), tap = ncp ? step / ncp : cs4 ? (step >> 1) : (step >> 2);
+        const int df = tap / 7, dh = tap % 7;
+        const int dw = ncp ? (kk >> 1) : cs4 ? 4 * ks + (kk >> 2) : 2 * ks + (kk >> 3);
+        const int c = ncp ? 2 * ks + (kk & 1) : cs4 ? (kk & 3) : (kk & 7);
         float v = 0.f;
         if (n < N && c < C && dw < 7) v = w[(((long long)n * C + c) * 7 + df) * 49 + dh * 7 + dw];
         if (h3) {
@@ -297,10 +457,11 @@ __global__ void pack_stem7x6_kernel(const float* __restrict__ w, unsigned short*
 
 int launch_pack_stem7x6(const float* w, void* wp6, int N, int Npad, int C, hipStream_t s) {
     const int cs4 = stem_cs4(C) ? 1 : 0;
-    const long long total = (cs4 ? 98ll : 196ll) * Npad * 16;
+    const int ncp = stem_ncp(C);
+    const long long total = (ncp ? 49ll * ncp : cs4 ? 98ll : 196ll) * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_stem7x6_kernel, dim3(grid), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp6), N, Npad, C,
-                       stem_h3() ? 1 : 0, cs4, f16x3_weight_overflow_flag());
+                       stem_h3() ? 1 : 0, cs4, ncp, f16x3_weight_overflow_flag());
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

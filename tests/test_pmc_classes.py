@@ -27,6 +27,7 @@ CASES = {
     "void dpc::igemm3w_kernel<false, 64>(dpc::IgemmParams, unsigned char const*)": "igemm_bn64",
     "void dpc::igemm3w_kernel<true, 128>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
     "void dpc::stem7x6_kernel<true, 8>(dpc::StemParams, unsigned char const*)": "stem_gather",
+    "void dpc::stem7p_kernel<3>(dpc::StemParams, unsigned char const*)": "stem_gather",
     "void dpc::tattn3_kernel<64, true, 0>(dpc::TattnParams, unsigned char const*, unsigned char const*, float*)": "temporal_attention_fused",
     "void dpc::lattn3_kernel<64>(dpc::LattnParams, unsigned char const*, unsigned char const*)": "linear_attention_fused",
     "dpc::gn_apply_kernel(float const*, float*, float const*, float const*, float const*, float const*, float const*, long long, int, int, int, int*)": "groupnorm_silu",

@@ -25,7 +25,7 @@ CLASSES = [
     (r"igemm3w_kernel<(true|false), 64>", "igemm_bn64"), (r"igemm3w_kernel<", "igemm_bn128"),
     (r"igemm3t_kernel<2,", "igemm_bn64"), (r"igemm3t_kernel<", "igemm_bn128"),                      # (pixel tiles: 64 -> 64 / 128 -> 128)
     (r"igemm[63]?_kernel<128", "igemm_bn128"), (r"igemm[63]?_kernel<64|conv1x1_rows_kernel", "igemm_bn64"),
-    (r"stem7x6_kernel|stem_kernel", "stem_gather"), (r"tattn(_fused|6|3w?)_kernel", "temporal_attention_fused"),
+    (r"stem7x6_kernel|stem7p_kernel|stem_kernel", "stem_gather"), (r"tattn(_fused|6|3w?)_kernel", "temporal_attention_fused"),
     (r"lattn(3|6?_(ctx|out))_kernel", "linear_attention_fused"), (r"gn_(partial|finalize|finalize_fused|apply)_kernel", "groupnorm_silu"),
     (r"ln_stats_kernel", "ln_stats"), (r"ddpm_update_smoke_kernel", "ddpm_update"),
     (r"philox_normal_kernel", "philox_normal"), (r"attention_kernel", "attention_core"),
