@@ -16,16 +16,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Filler { NONE = 0, FMA, FMA_DEP, CVT_PK, FMA_MIX, PK_FMA, EXP, DS_WRITE, DS_READ, MOV, NFILL };
+enum Filler { NONE = 0, FMA, FMA_DEP, CVT_PK, FMA_MIX, PK_FMA, EXP, DS_WRITE, DS_READ, MOV, MUL, MED3, NFILL };
 static const char* NAMES[NFILL] = {"(none)", "v_fma_f32 x8 independent", "v_fma_f32 dependent chain", "v_cvt_pk_f16_f32", "v_fma_mixlo_f16",
-                                   "v_pk_fma_f32", "v_exp_f32", "ds_write_b64", "ds_read_b128", "v_mov_b32"};
+                                   "v_pk_fma_f32", "v_exp_f32", "ds_write_b64", "ds_read_b128", "v_mov_b32", "v_mul_f32", "v_med3_f32"};
 
-constexpr int UNROLL = 16;          // filler instructions per loop iteration
+constexpr int UNROLL = 16;          // filler instructions per block
+constexpr int BLOCKS = 16;          // blocks per look at the `done` flag (an LDS read + wait: ~100 cycles)
 
 template <int F>
 __device__ __forceinline__ void filler_block(float (&r)[8], unsigned (&u)[4], unsigned char* lds, int lane) {
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) {
+        if constexpr (F == MUL) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r[i & 7]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]));
+        if constexpr (F == MED3) asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(r[i & 7]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]), "v"(r[(i + 3) & 7]));
         if constexpr (F == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i & 7]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]));
         if constexpr (F == FMA_DEP) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(r[0]) : "v"(r[1]));
         if constexpr (F == CVT_PK) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[i & 3]) : "v"(r[i & 7]), "v"(r[(i + 1) & 7]));
@@ -39,7 +42,24 @@ __device__ __forceinline__ void filler_block(float (&r)[8], unsigned (&u)[4], un
     if constexpr (F == DS_WRITE || F == DS_READ) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// out[block][0] = cycles of MFMA wave 0, [1] = filler iterations of wave 4
+template <int F, int K>
+__device__ __forceinline__ void same_wave(float (&r)[8], unsigned (&u)[4], int lane) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        if constexpr (F == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i & 7]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]));
+        if constexpr (F == MUL) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r[i & 7]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]));
+        if constexpr (F == MED3) asm volatile("v_med3_f32 %0, %1, %2, %3" : "=v"(r[i & 7]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]), "v"(r[(i + 3) & 7]));
+        if constexpr (F == CVT_PK) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[i & 3]) : "v"(r[i & 7]), "v"(r[(i + 1) & 7]));
+        if constexpr (F == FMA_MIX) asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "+v"(u[i & 3]) : "v"(r[i & 7]), "v"(u[(i + 1) & 3]));
+        if constexpr (F == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*reinterpret_cast<double*>(&r[2 * (i & 3)])) : "v"(*reinterpret_cast<double*>(&r[2 * ((i + 1) & 3)])));
+        if constexpr (F == EXP) asm volatile("v_exp_f32 %0, %1" : "=v"(r[i & 7]) : "v"(r[(i + 1) & 7]));
+        if constexpr (F == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i & 3]) : "v"(u[(i + 1) & 3]));
+        if constexpr (F == DS_WRITE) asm volatile("ds_write_b64 %0, %1" :: "v"(lane * 8 + (i & 3) * 512), "v"(*reinterpret_cast<double*>(&r[0])) : "memory");
+        if constexpr (F == DS_READ) asm volatile("ds_read_b128 %0, %1" : "=v"(*reinterpret_cast<f32x4*>(&r[4 * (i & 1)])) : "v"(lane * 16 + (i & 3) * 1024) : "memory");
+    }
+}
+
+// out[block][0] = cycles of MFMA wave 0, [1] = filler blocks of wave 4
 template <int F, int SAME_K>
 __global__ __launch_bounds__(512, 1) void coissue_kernel(unsigned long long* out, int n_mfma) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[8192];
@@ -67,14 +87,7 @@ __global__ __launch_bounds__(512, 1) void coissue_kernel(unsigned long long* out
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
-                if constexpr (SAME_K > 0) {
-#pragma unroll
-                    for (int j = 0; j < SAME_K; ++j) {
-                        if constexpr (F == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[j & 7]) : "v"(r[(j + 1) & 7]), "v"(r[(j + 2) & 7]));
-                        if constexpr (F == CVT_PK) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[j & 3]) : "v"(r[j & 7]), "v"(r[(j + 1) & 7]));
-                        if constexpr (F == FMA_MIX) asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "+v"(u[j & 3]) : "v"(r[j & 7]), "v"(u[(j + 1) & 3]));
-                    }
-                }
+                if constexpr (SAME_K > 0) same_wave<F, SAME_K>(r, u, lane);
             }
         }
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -89,8 +102,9 @@ __global__ __launch_bounds__(512, 1) void coissue_kernel(unsigned long long* out
         unsigned long long iters = 0;
         if constexpr (F != NONE && SAME_K == 0) {
             while (done < 4) {
-                filler_block<F>(r, u, lds, lane);
-                ++iters;
+#pragma unroll 1
+                for (int b = 0; b < BLOCKS; ++b) filler_block<F>(r, u, lds, lane);
+                iters += BLOCKS;
             }
         }
         if (wave == 4 && lane == 0) out[blockIdx.x * 4 + 1] = iters;
@@ -142,13 +156,22 @@ int main() {
     run<MOV, 0>(NAMES[MOV], d_out, nblk, n_mfma, base);
     run<DS_WRITE, 0>(NAMES[DS_WRITE], d_out, nblk, n_mfma, base);
     run<DS_READ, 0>(NAMES[DS_READ], d_out, nblk, n_mfma, base);
-    run<FMA, 2>("v_fma_f32, 2 per MFMA", d_out, nblk, n_mfma, base);
-    run<FMA, 4>("v_fma_f32, 4 per MFMA", d_out, nblk, n_mfma, base);
-    run<FMA, 6>("v_fma_f32, 6 per MFMA", d_out, nblk, n_mfma, base);
-    run<FMA, 8>("v_fma_f32, 8 per MFMA", d_out, nblk, n_mfma, base);
-    run<FMA, 12>("v_fma_f32, 12 per MFMA", d_out, nblk, n_mfma, base);
-    run<FMA_MIX, 6>("v_fma_mixlo_f16, 6 per MFMA", d_out, nblk, n_mfma, base);
-    run<CVT_PK, 6>("v_cvt_pk_f16_f32, 6 per MFMA", d_out, nblk, n_mfma, base);
+    run<MUL, 0>(NAMES[MUL], d_out, nblk, n_mfma, base);
+    run<MED3, 0>(NAMES[MED3], d_out, nblk, n_mfma, base);
+    printf("--- fillers issued by the MFMA wave itself, K per MFMA\n");
+#define SAME(F, NAME) run<F, 2>(NAME ", 2 per MFMA", d_out, nblk, n_mfma, base); run<F, 4>(NAME ", 4 per MFMA", d_out, nblk, n_mfma, base); \
+                      run<F, 6>(NAME ", 6 per MFMA", d_out, nblk, n_mfma, base); run<F, 8>(NAME ", 8 per MFMA", d_out, nblk, n_mfma, base); \
+                      run<F, 12>(NAME ", 12 per MFMA", d_out, nblk, n_mfma, base)
+    SAME(FMA, "v_fma_f32");
+    SAME(MUL, "v_mul_f32");
+    SAME(MED3, "v_med3_f32");
+    SAME(CVT_PK, "v_cvt_pk_f16_f32");
+    SAME(FMA_MIX, "v_fma_mixlo_f16");
+    SAME(PK_FMA, "v_pk_fma_f32");
+    SAME(EXP, "v_exp_f32");
+    SAME(MOV, "v_mov_b32");
+    SAME(DS_READ, "ds_read_b128");
+    SAME(DS_WRITE, "ds_write_b64");
     hipFree(d_out);
     return 0;
 }
