@@ -1,12 +1,20 @@
 """Repeat the Burgers two-rank-vs-one-rank entry-script comparison of tests/test_gpu_inference_scripts.py N times and print every
 J_actual / Energy value (flake hunting: one full-suite run of r03 saw the two-rank result differ once).
   gpurun -- 'python tools/rank_stress.py [repeats] [graph 0/1]'
+  gpurun -- 'python tools/rank_stress.py solo [repeats]'     one rank ALONE on the GPU at batch 1 and batch 2 (the shard sizes of the
+                                                             two-rank run): separates "small-batch path is not repeatable" from
+                                                             "two processes time-sharing the GPU"
+r03 (profiles/r03_bh_rank_stress.log, 70 repeats): 6 "mismatches" were the launcher's shared pipe interleaving the ranks' output
+mid-line (fixed in run_ranks: per-rank files), 2 were real: J_actual 0.91172576 / 0.91172546 against 0.91172606 (3e-7 relative).
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_inference_scripts as T
 
+solo = len(sys.argv) > 1 and sys.argv[1] == "solo"
+if solo:
+    sys.argv.pop(1)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 if len(sys.argv) > 2:
     os.environ["DPC_BURGERS_GRAPH"] = sys.argv[2]
@@ -18,11 +26,26 @@ args = ["inference/inference_1d_burgers.py", "--dataset", "free_u_f_1e5_front_re
         "--is_model_w", "False", "--eval_two_models", "True", "--prior_beta", "0.9", "--w_scheduler", "sigmoid_flip",
         "--wus", "0.5", "--synthetic", "True", "--n_test_samples", "3", "--batch_size", "3", "--timesteps_override", "6"]
 vals = lambda out: tuple(repr(T._floats_after(out, k)) for k in ("J_actual:", "Energy:"))
+if solo:
+    for bs in (1, 2):
+        a = list(args)
+        a[a.index("--n_test_samples") + 1] = str(bs)
+        a[a.index("--batch_size") + 1] = str(bs)
+        ref = vals(T.run(a, ROOT))
+        diff = 0
+        for i in range(n):
+            v = vals(T.run(a, ROOT))
+            if v != ref:
+                diff += 1
+                print("batch", bs, "repeat", i, v, "!=", ref, flush=True)
+        print("batch", bs, ":", n, "repeats alone,", diff, "differ from the first run", ref, flush=True)
+    sys.exit(0)
 ref = vals(T.run(args, ROOT))
 print("one rank ", ref, flush=True)
 bad = 0
+skip_one = os.environ.get("RANK_STRESS_SKIP_ONE") == "1"      # (hypothesis runs: only the two-rank leg, twice as many per GPU-minute)
 for i in range(n):
-    one = vals(T.run(args, ROOT))
+    one = ref if skip_one else vals(T.run(args, ROOT))
     two = vals(T.run_ranks(2, args, ROOT))
     if one != ref or two[0].count(eval(ref[0])[-1].__repr__()) == 0:
         pass
