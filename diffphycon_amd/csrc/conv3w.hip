@@ -499,26 +499,37 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
         for (int kc = 0; kc < kchunks; ++kc) {
-            lda_pair(0, 0);
-            lda_pair(0, 1);
+            lda_pair(0, 0);                               // (set 1 follows four MFMAs into the first tap, see tap_body)
             auto tap_body = [&](int tap) {
                 ldw(w[(tap + 2) % 3]);                    // two taps ahead (the ring runs on across chunks and tiles)
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};     // small terms first; PA: activation plane, PB: weight plane
+                // Fragment re-loads (r03): a set is re-loaded FOUR MFMAs after the last MFMA that reads it was issued, and eight MFMAs
+                // before its next reader -- set 1 (pair 1 of this tap) inside group (tap, 0), set 0 (pair 0 of the next tap) inside
+                // group (tap, 1).  The earlier order issued the ds_read right behind the group that had just read the set and relied
+                // on "an MFMA starts within its 32-cycle slot, the LDS return needs >= 64 cycles": true only while no foreign wave
+                // issues MFMAs on the SIMD -- two processes sharing the GPU produced one wrong fragment element now and then
+                // (third hazard; tools/rank_stress.py).  Same MFMA order: results are bit-identical.
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
 #pragma unroll
-                    for (int term = 0; term < 3; ++term)
+                    for (int term = 0; term < 3; ++term) {
+                        if (term == 1) {
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (pr == 0) lda_pair(tap, 1);
+                            else if (tap < NTAPS - 1) lda_pair(tap + 1, 0);
+                            asm volatile("" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[2 * pr + q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                     w[tap % 3][nt][PB[term]], a[2 * pr + q][PA[term]], acc[2 * pr + q][nt], 0, 0, 0);
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (tap < NTAPS - 1) lda_pair(tap + 1, pr);   // rolling A set: re-load behind the other pair's MFMAs
+                    }
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }

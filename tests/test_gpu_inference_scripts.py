@@ -104,13 +104,11 @@ def test_burgers_script_two_ranks_match_single_rank():
         return bad
     bad = compare()
     if bad:
-        # r03 stress runs (tools/rank_stress.py, profiles/r03_bh / r03_bi / r03_bk_*): 2 of 70 two-rank runs gave J_actual 3e-7
-        # (relative) off the single-rank value; 82 single-rank repeats, 120 repeats of the shard sizes alone on the GPU and 130
-        # two-rank runs with the halo convolution kernel switched off were all bit-equal.  The two ranks here time-share ONE GPU
-        # -- a configuration no deployment has (one process per GPU; RCCL refuses two ranks on a device) -- and a foreign wave on
-        # the SIMD breaks the timing guard of the halo kernels' MFMA operand re-load (third hazard).  A mismatch
-        # that an immediate re-run reproduces is a sharding bug and fails; one that does not is reported loudly instead of ending
-        # the whole GPU run.
+        # r03 stress runs (tools/rank_stress.py, profiles/r03_bh / r03_bi / r03_bk / r03_bl_*): 2 of 70 two-rank runs gave J_actual
+        # 3e-7 (relative) off the single-rank value -- two processes time-sharing ONE GPU broke the timing guard of the halo
+        # convolution kernels' MFMA operand re-load (third hazard).  Fixed (re-loads four MFMAs behind their last
+        # reader): 0 of 110 since.  The re-run stays as a tripwire: a mismatch that an immediate re-run reproduces is a sharding
+        # bug and fails; one that does not is reported loudly instead of ending the whole GPU run.
         again = compare()
         assert not again, ("two-rank result differs from the single-rank result in two consecutive runs", bad, again)
         import warnings
