@@ -1,6 +1,7 @@
 """Repeat the Burgers two-rank-vs-one-rank entry-script comparison of tests/test_gpu_inference_scripts.py N times and print every
 J_actual / Energy value (flake hunting: one full-suite run of r03 saw the two-rank result differ once).
   gpurun -- 'python tools/rank_stress.py [repeats] [graph 0/1]'
+  gpurun -- 'python tools/rank_stress.py smoke [repeats]'    the smoke entry script (3-D denoisers) instead of the Burgers one
   gpurun -- 'python tools/rank_stress.py solo [repeats]'     one rank ALONE on the GPU at batch 1 and batch 2 (the shard sizes of the
                                                              two-rank run): separates "small-batch path is not repeatable" from
                                                              "two processes time-sharing the GPU"
@@ -13,7 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_inference_scripts as T
 
 solo = len(sys.argv) > 1 and sys.argv[1] == "solo"
-if solo:
+smoke = len(sys.argv) > 1 and sys.argv[1] == "smoke"
+if solo or smoke:
     sys.argv.pop(1)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 if len(sys.argv) > 2:
@@ -26,6 +28,25 @@ args = ["inference/inference_1d_burgers.py", "--dataset", "free_u_f_1e5_front_re
         "--is_model_w", "False", "--eval_two_models", "True", "--prior_beta", "0.9", "--w_scheduler", "sigmoid_flip",
         "--wus", "0.5", "--synthetic", "True", "--n_test_samples", "3", "--batch_size", "3", "--timesteps_override", "6"]
 vals = lambda out: tuple(repr(T._floats_after(out, k)) for k in ("J_actual:", "Energy:"))
+if smoke:
+    # the smoke entry script (Unet3D denoisers: conv3w / conv3f3c, fused attention, panel / tile implicit GEMM, stem): two ranks on one
+    # GPU against one rank, the test's arguments; every rank prints the gathered metrics
+    import tempfile
+    sargs = ["inference/inference_2d_smoke.py", "--synthetic", "True", "--n_test", "3", "--batch_size", "1", "--ddim_sampling_steps", "2"]
+    keys = ("J_total:", "J_target:", "mse:", "n_l2:")
+    sv = lambda out: tuple(repr(T._floats_after(out, k)[-1:]) for k in keys)
+    with tempfile.TemporaryDirectory() as td:
+        ref = sv(T.run(sargs + ["--inference_result_path", td + "/a"], ROOT))
+        print("one rank ", ref, flush=True)
+        bad = 0
+        for i in range(n):
+            out = T.run_ranks(2, sargs + ["--inference_result_path", td + f"/b{i}"], ROOT)
+            allv = [T._floats_after(out, k) for k in keys]
+            ok = all(repr([x]) == r for vs, r in zip(allv, ref) for x in vs)
+            bad += not ok
+            print(i, "two ranks", "same" if ok else allv, flush=True)
+        print("mismatches", bad)
+    sys.exit(0)
 if solo:
     for bs in (1, 2):
         a = list(args)
