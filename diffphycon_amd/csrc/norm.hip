@@ -213,8 +213,9 @@ __device__ __forceinline__ void gn_apply_rows(const float* x, float* out, const 
             const long long ru = r + (long long)u * rpp;
             ok[u] = ru < r_end;
             const long long o = (ok[u] ? ru : r) * C + c4 * 4;
-            v[u] = *reinterpret_cast<const f32x4*>(xb + o);
-            if (rb) q[u] = *reinterpret_cast<const f32x4*>(rb + o);
+            // (non-temporal: every byte of this pass is touched once -- 12.0 -> 11.3 ms per S64 step for the class, r03_bs)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + o));
+            if (rb) q[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rb + o));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -227,7 +228,7 @@ __device__ __forceinline__ void gn_apply_rows(const float* x, float* out, const 
             if (rb) v[u] += q[u];
             if (ok[u]) {
                 omx = max(omx, max(max(abs_bits(v[u][0]), abs_bits(v[u][1])), max(abs_bits(v[u][2]), abs_bits(v[u][3]))));
-                *reinterpret_cast<f32x4*>(ob + (r + (long long)u * rpp) * C + c4 * 4) = v[u];
+                __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(ob + (r + (long long)u * rpp) * C + c4 * 4));
             }
         }
     }
