@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # batch-size dependent results at full size; the build fails instead of shipping one.
 # conv3w_kernel: its loader waves count their own vmcnt -- a compiler-inserted scratch reload there waits for every load in flight.
 NO_SPILL = {"igemm6.hip": ("igemm3_kernel",), "conv3w.hip": ("conv3w_kernel",), "igemm_wide.hip": ("igemm3w_kernel",),
-            "igemm_panel.hip": ("igemm3p_kernel",), "igemm_tile.hip": ("igemm3t_kernel",)}
+            "igemm_panel.hip": ("igemm3p_kernel",), "igemm_tile.hip": ("igemm3t_kernel",), "stem7x6.hip": ("stem7p_kernel",)}
 
 
 def sources():
