@@ -21,7 +21,12 @@ The JSON line also carries
   value_exact  : the same timed loop re-run with exact fp32 products (arithmetic mode x6: 3-way bf16 split) -- the default
                  mode (f16x3) carries 22 significant operand bits;
   burgers      : BASELINE.json configs[1] (Burgers POPC, B=256/GPU) measured in the same run, with its own roofline/cpu_baseline;
-  smoke_evaluator : rollouts/s of the post-sampling PDE evaluator (N=1 only).
+  smoke_evaluator : rollouts/s of the post-sampling PDE evaluator (N=1 only);
+  roofline_step / roofline_exact : the whole step's algorithmic TFLOP/s against the same roof; the dominant class of the x6 leg;
+  ddim100 / e2e   : ONE real pass each of the entry script's pipeline (sample() + PDE evaluator + metric rows) at B=64 per GPU: the
+                    CLI default DDIM-100 and the full 1000-step DDPM; wall seconds, nothing extrapolated; e2e checks that its
+                    measured ms per step agrees with the timed loop's within 2 % (--no-e2e skips both: ~5 minutes);
+  every leg carries its per-rank min/max step time and the world size RCCL reported.
 """
 import argparse
 import json
@@ -69,6 +74,25 @@ def mfma_roof(kernel_class, modes):
     if mode == "x6":
         return PEAK_BF16_MFMA_TFLOPS / 6.0, "2500 TF bf16 dense / 6 MFMAs per fp32 product (bf16x6 split)"
     return PEAK_BF16_MFMA_TFLOPS / 3.0, "2500 TF fp16 dense / 3 MFMAs per fp32 product (f16x3 split)"
+
+
+def dtype_label(modes):
+    """What the `dtype` field says: tensors in HBM and every accumulation are fp32; the PRODUCTS of the GEMM-shaped kernels are formed
+    from split 16-bit operands in the arithmetic mode the library reports (f16x3: 22 significant operand bits, 3 MFMAs per product;
+    x6: exact 3-way bf16 split, 6 MFMAs; f32: the native fp32 MFMA)."""
+    md = sorted(set(kv.split("=")[1] for kv in modes.split(","))) if modes else ["f32"]
+    if md == ["f32"]:
+        return "f32"
+    return "f32 storage/accumulate; " + "/".join(md) + " products"
+
+
+def step_roofline(modes, flop_per_step, sec_per_step, note):
+    """Whole-step figure next to the dominant kernel's: ALGORITHMIC flop of one step / measured step time against the MFMA roof of the
+    arithmetic mode of the convolution family (where > 90 % of the flop are)."""
+    peak, peak_note = mfma_roof("conv3x6_bn64", modes)
+    achieved = flop_per_step / sec_per_step / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+            "peak_note": peak_note, "note": note}
 
 
 def pmc_traffic(kernel_class):
@@ -248,6 +272,7 @@ class Ctx:
 
     def __init__(self, rank, world, device, dist, stub=False):
         self.rank, self.world, self.device, self.dist, self.stub = rank, world, device, dist, stub
+        self.seen_world = dist.get_world_size() if dist is not None else 1      # what the backend (RCCL / gloo) itself reports
 
     def sync(self):
         if not self.stub:
@@ -364,10 +389,10 @@ def run_burgers(ctx, args, t_start, batch=256, with_cpu=True, exact=True):
     modes = gd.model_uw.modes
     out = {"metric": "guided trajectories/sec, 1D Burgers POPC 128 cells x 10 steps @1000 DDPM steps",
            "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": ctx.world,
-           "steps": args.steps, "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "dtype": "f32",
+           "steps": args.steps, "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "dtype": dtype_label(modes),
            "launch_mode": ("denoiser forwards replayed from a HIP graph (torch.cuda.CUDAGraph), update kernels eager"
                            if gd.use_graph else "eager launches"),
-           "ms_per_step_eager_profiled": sec_e * 1e3,
+           "ms_per_step_eager_profiled": sec_e * 1e3, "world_size_seen_by_rccl": ctx.seen_world,
            "arithmetic": modes,
            "config": {"workload": "Burgers POPC (BASELINE.json configs[1]): 128 cells x 10 steps (16x128 padded), "
                                   f"1000-step guided DDPM, batch={batch} per GPU; one step = prepare + joint Unet2D(dim 64, "
@@ -376,6 +401,8 @@ def run_burgers(ctx, args, t_start, batch=256, with_cpu=True, exact=True):
     if ctx.rank == 0:
         out["roofline"] = roofline_of(prof, prof_all, modes, sec_e, args.steps, warm_ms, batch * BURGERS_UNIT_GFLOP / 1e3)
         out["roofline"]["note"] = "per-kernel events need eager launches: measured on the eager leg (ms_per_step_eager_profiled)"
+        out["roofline_step"] = step_roofline(modes, batch * BURGERS_UNIT_GFLOP * 1e9, sec,
+                                             f"{batch} x {BURGERS_UNIT_GFLOP} GFLOP (SURVEY.md 8d) per step / ms_per_step")
     ctx.log(t_start, f"burgers: {sec * 1e3:.2f} ms/step ({sec_e * 1e3:.2f} eager with events)")
     if exact:
         gd_x, _, _, _ = burgers_setup(ctx.device, batch, ctx.rank, arithmetic="x6")
@@ -424,7 +451,8 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
     out = {"metric": "training samples/sec, 2D smoke 64x64x32 joint denoiser (p_losses forward + backward + clip + Adam + EMA)",
            "value": ctx.world * batch / sec, "unit": "samples/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": dtype_label(getattr(gd.model, "modes", "")), "data": "synthetic",
+           "world_size_seen_by_rccl": ctx.seen_world,
            "arithmetic": f"forward {gd.model.modes if hasattr(gd.model, 'modes') else ''}; backward-data convolutions {bwd_mode}"
                          f" (loss scale {loss_scale:g}); weight gradients exact fp32 products on the native fp32 MFMA",
            "loss_first_last": [first, last],
@@ -471,7 +499,9 @@ def run_s128_leg(ctx, args, t_start, batch=8):
     assert torch.isfinite(x).all()
     ctx.log(t_start, f"s128: {sec * 1e3:.1f} ms/step")
     return {"metric": "guided trajectories/sec, 2D smoke 128x128x64 @1000 DDPM steps", "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec),
-            "unit": "trajectories/s", "n_gpus": ctx.world, "steps": args.steps, "ms_per_step": sec * 1e3, "dtype": "f32",
+            "unit": "trajectories/s", "n_gpus": ctx.world, "steps": args.steps, "ms_per_step": sec * 1e3,
+            "ms_per_step_min_rank": sec_min * 1e3, "world_size_seen_by_rccl": ctx.seen_world, "dtype": dtype_label(gd.model_joint.modes),
+            "roofline_step": step_roofline(gd.model_joint.modes, batch * 14534.0e9, sec, f"{batch} x 14534 GFLOP (SURVEY.md 8d) per step / ms_per_step"),
             "config": {"workload": f"S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU, micro-batch 4",
                        "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
 
@@ -502,16 +532,82 @@ def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
         times[T] = time.perf_counter() - t0
         del ppl, diffusion, force_model, bd_updater, design_fn
         torch.cuda.empty_cache()
-    sec, _ = ctx.reduce((times[20] - times[4]) / 16)
+    sec, sec_min = ctx.reduce((times[20] - times[4]) / 16)
     ctx.log(t_start, f"j128: {sec * 1e3:.1f} ms per guided step")
     return {"metric": f"guided trajectories/sec, 2D jellyfish {image_size}x{image_size}x{frames} @1000 DDPM steps",
             "value": ctx.world * batch / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": ctx.world,
-            "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "world_size_seen_by_rccl": ctx.seen_world,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 storage/accumulate; f16x3 products", "data": "synthetic",
             "config": {"workload": f"J128 (BASELINE.json configs[3]): 2D jellyfish full-obs {image_size}x{image_size} x {frames} "
                                    f"frames, joint+prior Unet3D reweighted + design gradient on libdpc, batch={batch} per GPU; "
                                    "per-step time = (20-step run - 4-step run) / 16 of the entry script's pipeline",
                        "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
+
+
+def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
+    """ONE real pass of the entry script's pipeline (inference/inference_2d_smoke.py main() on the synthetic test split, the
+    reference's :179-197 + :317-427): `GaussianDiffusion.sample()` of `batch` trajectories per GPU -- 1000 guided DDPM steps
+    (ddim=False) or the script's CLI default DDIM-100 (ddim=True, :511-517) -- then the PDE evaluator (solver_batch) + multi_evaluate,
+    metric rows gathered over the ranks as the script does.  Nothing is extrapolated: seconds are wall seconds of that pass."""
+    sys.path.insert(0, os.path.join(ROOT, "inference"))
+    import inference_2d_smoke as S
+    a = S.build_parser().parse_args(["--synthetic", "True", "--batch_size", str(batch), "--n_test", str(batch * ctx.world),
+                                     "--using_ddim", str(bool(ddim)), "--ddim_sampling_steps", "100",
+                                     "--inference_result_path", "/tmp/dpc_bench_e2e"])
+    a.device, a.rank, a.world_size = ctx.device, ctx.rank, ctx.world
+    a.inference_result_subpath = os.path.join(a.inference_result_path, f"{'ddim' if ddim else 'ddpm'}_{os.getpid()}")
+    torch.manual_seed(0)                      # the same two random-init denoisers as the headline loop (build_models)
+    with contextlib.redirect_stdout(sys.stderr):
+        loader, rescaler = S.load_data(a)
+        diffusion, design_fn = S.load_model(a, rescaler, a.w_energy, w_init=a.w_init)
+        ppl = S.InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": a.design_guidance}, rescaler,
+                                  results_path=a.inference_result_subpath, args_general=a)
+        # warm-up outside the timed pass: weight upload + packing, workspace allocation, module load of the evaluator
+        st0 = next(iter(loader))[0][:2]
+        tiny = diffusion[0].sampling_timesteps, diffusion[0].is_ddim_sampling
+        diffusion[0].sampling_timesteps, diffusion[0].is_ddim_sampling = 2, True
+        ppl.multi_evaluate(ppl.run_model(st0), st0)
+        diffusion[0].sampling_timesteps, diffusion[0].is_ddim_sampling = tiny
+        spent = {"sample": 0.0, "evaluate": 0.0}
+
+        def timed(name, fn):
+            def wrapped(*x, **kw):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = fn(*x, **kw)
+                torch.cuda.synchronize()
+                spent[name] += time.perf_counter() - t0
+                return out
+            return wrapped
+        ppl.run_model = timed("sample", ppl.run_model)
+        ppl.multi_evaluate = timed("evaluate", ppl.multi_evaluate)
+        ctx.sync()
+        t0 = time.perf_counter()
+        J = ppl.run(loader)
+        ctx.sync()
+        total = time.perf_counter() - t0
+    total, _ = ctx.reduce(total)
+    samp, samp_min = ctx.reduce(spent["sample"])
+    evl, _ = ctx.reduce(spent["evaluate"])
+    steps = 100 if ddim else STEPS_PER_TRAJECTORY
+    out = {"pipeline": "inference/inference_2d_smoke.py main(): sample() + solver_batch + multi_evaluate, synthetic test split, "
+                       f"random-init denoisers, {'DDIM-100, eta 1 (the CLI default)' if ddim else '1000-step guided DDPM'}",
+           "batch_per_gpu": batch, "n_gpus": ctx.world, "world_size_seen_by_rccl": ctx.seen_world, "sampling_steps": steps,
+           "sample_seconds": samp, "sample_seconds_min_rank": samp_min, "evaluate_seconds": evl, "wall_seconds": total,
+           "trajectories_per_s_sampling": ctx.world * batch / samp, "trajectories_per_s_end_to_end": ctx.world * batch / total,
+           "ms_per_step_measured": samp / steps * 1e3, "unit": "trajectories/s", "measured": "wall clock of one complete pass, not extrapolated",
+           "metric_row": {k: float(v.reshape(-1)[0]) for k, v in J.items()}}
+    if ms_per_step is not None:
+        ratio = (samp / steps * 1e3) / ms_per_step
+        out["vs_headline_ms_per_step"] = ratio
+        out["agrees_with_headline_within_2pct"] = bool(abs(ratio - 1.0) <= 0.02)
+        if not out["agrees_with_headline_within_2pct"]:
+            ctx.log(t_start, f"WARNING: e2e ms per step is {ratio:.4f} x the timed-loop ms_per_step (expected within 2 %)")
+    ctx.log(t_start, f"e2e {'ddim100' if ddim else 'ddpm1000'}: sample {samp:.1f} s + evaluate {evl:.1f} s")
+    del ppl, diffusion
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_smoke_evaluator(ctx, B=64, T=256):
@@ -559,7 +655,7 @@ def self_launch(args, argv):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128", "train", "j128"],
+    ap.add_argument("--workload", default="smoke", choices=["smoke", "burgers", "s128", "train", "j128", "e2e", "ddim100"],
                     help="smoke = BASELINE.json's headline metric S64 (default); burgers = configs[1]; s128 = configs[4] shape "
                          "(128x128x64 frames; builder-side line, batch 8 per GPU by default)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -570,6 +666,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of host time for all cpu_baseline legs")
     ap.add_argument("--no-extras", action="store_true", help="headline loop only: no exact-mode / burgers / evaluator legs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the two real end-to-end passes (DDIM-100: ~30 s, DDPM-1000: ~270 s)")
     ap.add_argument("--stub", action="store_true",
                     help="TEST ONLY: CPU + gloo, the step is a sleep; exercises the launcher / barrier / reduction plumbing")
     args = ap.parse_args()
@@ -598,7 +695,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL over xGMI
     ctx = Ctx(rank, world, device, dist, stub=args.stub)
-    seen_world = dist.get_world_size() if dist is not None else 1
+    seen_world = ctx.seen_world
     launcher = "self (bench.py -> torch.distributed.run)" if os.environ.get("DPC_BENCH_SELF_LAUNCHED") else \
         ("external torch.distributed.run" if world > 1 else "single process")
 
@@ -643,6 +740,16 @@ def main():
         if rank == 0:
             out.update({"steps": 16, "warmup": 4, "world_size_seen_by_rccl": seen_world, "launcher": launcher, "roofline": None,
                         "cpu_baseline": None})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.workload in ("e2e", "ddim100"):
+        out = run_e2e(ctx, args, t_start, ddim=args.workload == "ddim100", batch=args.batch or LOCAL_BATCH)
+        if rank == 0:
+            out.update({"launcher": launcher, "roofline": None, "cpu_baseline": None})
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
@@ -703,7 +810,7 @@ def main():
                        "guided trajectories/sec, 2D smoke 64x64x32 @1000 DDPM steps"),
             "value": world * B / (STEPS_PER_TRAJECTORY * sec), "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype_label(modes), "data": "synthetic",
             "arithmetic": modes + " (reported by the library: dpc_unet3d_modes). fp32 tensors in HBM and fp32 accumulation "
                           "everywhere; f16x3 = each fp32 operand split into 2 fp16 terms (22 significant bits), 3 MFMAs per "
                           "product; x6 = exact 3-way bf16 split, 6 MFMAs; f32 = native fp32 MFMA. value_exact re-times the same "
@@ -716,18 +823,25 @@ def main():
                        "global_batch": world * B, "micro_batch": mbatch, "parallelism": f"batch-shard x{world}"},
             "world_size_seen_by_rccl": seen_world, "launcher": launcher,
             "roofline": roof,
+            "roofline_step": step_roofline(modes, B * unit_gflop * 1e9, sec,
+                                           f"{B} x {unit_gflop} GFLOP (SURVEY.md 8d: both U-Nets, direct-form flop) per step / ms_per_step"),
         }
     if not args.no_extras:
         # ---- exact-product leg: same loop, arithmetic mode x6 (3-way bf16 split of both operands, 6 MFMAs per fp32 product)
         del step, x
         gd_x, _ = build_models(device, mbatch, arithmetic="x6", frames=frames, size=size)
         step_x, x_x = make_step(gd_x)
-        sec_x, _, _, _, _ = timed_loop(ctx, step_x, min(args.steps, 5), 1, profile=False)
+        steps_x = min(args.steps, 5)
+        sec_x, _, prof_all_x, prof_x, warm_ms_x = timed_loop(ctx, step_x, steps_x, 1)
         assert torch.isfinite(x_x).all()
         if rank == 0:
             out["value_exact"] = world * B / (STEPS_PER_TRAJECTORY * sec_x)
             out["ms_per_step_exact"] = sec_x * 1e3
             out["arithmetic_exact"] = gd_x.model_joint.modes
+            out["dtype_exact"] = dtype_label(gd_x.model_joint.modes)
+            out["roofline_exact"] = roofline_of(prof_x, prof_all_x, gd_x.model_joint.modes, sec_x, steps_x, warm_ms_x, B * unit_gflop / 1e3)
+            out["roofline_exact"]["traffic"], out["roofline_exact"]["traffic_source"] = None, None   # (PMC passes cover the default mode)
+            out["roofline_step_exact"] = step_roofline(gd_x.model_joint.modes, B * unit_gflop * 1e9, sec_x, "as roofline_step, x6 leg")
         del gd_x, step_x, x_x
         torch.cuda.empty_cache()
         ctx.log(t_start, f"exact-mode leg done: {sec_x * 1e3:.1f} ms/step")
@@ -747,6 +861,10 @@ def main():
             legs["s128"] = run_s128_leg(ctx, extra, t_start)
             legs["j128"] = run_j128(ctx, extra, t_start)
             legs["train"] = run_train(ctx, extra, t_start, with_cpu=False)
+            # the CLI default (DDIM-100) and ONE real 1000-step trajectory batch through the entry script's pipeline, evaluator included
+            if not args.no_e2e:
+                legs["ddim100"] = run_e2e(ctx, args, t_start, ddim=True)
+                legs["e2e"] = run_e2e(ctx, args, t_start, ddim=False, ms_per_step=sec * 1e3)
             if rank == 0:
                 out.update(legs)
     if rank == 0:

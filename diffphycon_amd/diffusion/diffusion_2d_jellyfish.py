@@ -3,8 +3,10 @@
 
 Per step: joint Unet3D forward (7 -> 4 channels) + theta Unet3D forward (7 -> 1) on libdpc, ONE posterior kernel
 (dpc_ddpm_update_jelly), the design gradient through the two learned 2-D surrogates (model/surrogates_hip.py: forward and
-backward on libdpc; or any callable, e.g. `force_fn` below on the torch modules + autograd), ONE guidance kernel (dpc_jelly_apply_guidance), the boundary updater forward and the conditioning writes.
-`Unet` / `ForceUnet` (the surrogates) and `force_fn` / `reg_theta` keep the reference's names."""
+backward on libdpc -- the reference's `force_fn`, inference_2d_jellyfish.py:85-114, as an explicit reverse pass; the autograd
+restatement of it lives in tests/torch_force_fn.py as the test reference), ONE guidance kernel (dpc_jelly_apply_guidance), the
+boundary updater forward and the conditioning writes.
+`Unet` / `ForceUnet` (the surrogates' checkpoint containers) and `reg_theta` keep the reference's names."""
 import ctypes as C
 import math
 
@@ -22,25 +24,6 @@ def reg_theta(theta):
     """inference_2d_jellyfish.py:49-61: sum_t (theta_{t+1} - theta_t)^2."""
     d = theta[:, 1:] - theta[:, :-1]
     return torch.sum(d * d, dim=1)
-
-
-def force_fn(x, bd_0, force_model, bd_updater, args):
-    """inference_2d_jellyfish.py:85-114 (args: only_vis_pressure, device, reg_ratio, p_min, p_max)."""
-    if args.only_vis_pressure:
-        state, theta_expand = x[:, :, :1], x[:, :, -1]
-    else:
-        state, theta_expand = x[:, :, :3], x[:, :, 3]
-    state.requires_grad_()
-    theta_expand.requires_grad_()
-    theta = torch.mean(torch.mean(theta_expand, dim=3), dim=2)
-    pressure = state[:, :, 0] if args.only_vis_pressure else state[:, :, 2]
-    pressure = (0.5 * pressure + 0.5) * (args.p_max - args.p_min) + args.p_min          # unnormalize_state :40-41
-    pred_bd = bd_updater(bd_0.reshape(-1, *bd_0.shape[2:]), theta.reshape(-1)).reshape(bd_0.shape)
-    inp = torch.cat((pressure.unsqueeze(2), pred_bd), dim=2)
-    force = force_model(inp.reshape(-1, *inp.shape[2:])).reshape(state.shape[0], state.shape[1])
-    weight = torch.arange(force.shape[1], 0, -1, dtype=torch.float32, device=force.device).expand(force.shape[0], force.shape[1])
-    guidance = -torch.mean(force * weight, dim=1) + args.reg_ratio * reg_theta(theta)
-    return torch.autograd.grad(guidance, [state, theta_expand], grad_outputs=torch.ones_like(guidance))
 
 
 class GaussianDiffusion(nn.Module):
@@ -161,10 +144,10 @@ class GaussianDiffusion(nn.Module):
         return eps_j, self.model_thetas(x_w, t_b)
 
     def _design(self, design_fn, x0, bd_0_expand):
-        if getattr(design_fn, "analytic", False):          # HipDesignGradient: explicit backward pass, no autograd graph
-            return design_fn(x0, bd_0_expand)
-        with torch.enable_grad():
-            return design_fn(x0.clone().detach().requires_grad_(), bd_0_expand)
+        if not getattr(design_fn, "analytic", False):
+            raise TypeError("design_fn must be a diffphycon_amd HipDesignGradient (model/surrogates_hip.py: the design gradient of "
+                            "inference_2d_jellyfish.py:85-114 as an explicit reverse pass on libdpc); autograd closures are not on the HIP path")
+        return design_fn(x0, bd_0_expand)
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()

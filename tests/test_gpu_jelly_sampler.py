@@ -38,9 +38,8 @@ def env(dev):
     args = argparse.Namespace(only_vis_pressure=False, device=dev, reg_ratio=float(g["reg_ratio"]), p_min=float(g["p_min"]),
                               p_max=float(g["p_max"]))
 
-    def design_fn(x, bd0e):
-        gs, gt = DJ.force_fn(x, bd0e, fm, bd, args)
-        return torch.cat([gs, gt.unsqueeze(2)], dim=2)
+    from torch_force_fn import design_fn_torch
+    design_fn = design_fn_torch(fm, bd, args)        # the reference's force_fn on the torch modules + autograd (test reference)
 
     def make(tag):
         guid, kw = KW[tag]

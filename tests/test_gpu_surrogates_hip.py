@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import load_golden
+from torch_force_fn import force_fn
 
 pytestmark = pytest.mark.gpu
 
@@ -274,7 +275,7 @@ def test_design_gradient_matches_the_reference_record(sampler_env, dev):
     args0 = argparse.Namespace(**{**vars(args), "reg_ratio": 0.0})
     from diffphycon_amd.diffusion import diffusion_2d_jellyfish as DJ
     x = torch.from_numpy(g["grad:x"]).to(dev)
-    gs, gt = DJ.force_fn(x.clone(), bd0e, fm, bd, args0)
+    gs, gt = force_fn(x.clone(), bd0e, fm, bd, args0)
     got0 = SH.HipDesignGradient(fm, bd, args0)(x, bd0e)
     assert rel(got0[:, :, 3], gt) < 1e-4 and rel(got0[:, :, 2], gs[:, :, 2]) < 1e-4
 
@@ -294,7 +295,7 @@ def test_design_gradient_full_width_nets_vs_autograd(dev):
     B, T = 2, 3
     x = torch.rand(B, T, 4, 32, 32, device=dev) * 2 - 1
     bd0e = torch.rand(B, 1, 3, 32, 32, device=dev).expand(-1, T, -1, -1, -1).contiguous()
-    gs, gt = DJ.force_fn(x.clone(), bd0e, fm, bd, args)
+    gs, gt = force_fn(x.clone(), bd0e, fm, bd, args)
     design = SH.HipDesignGradient(fm, bd, args)
     got = design(x, bd0e)
     assert rel(got[:, :, 2], gs[:, :, 2]) < 1e-4
@@ -304,6 +305,53 @@ def test_design_gradient_full_width_nets_vs_autograd(dev):
     with torch.no_grad():
         ref = bd(bd0e.reshape(-1, 3, 32, 32), th)
     assert rel(design.unet(bd0e.reshape(-1, 3, 32, 32), th), ref) < 2e-5
+
+
+def test_design_gradient_at_the_j128_extent_vs_autograd(dev):
+    """BASELINE.json configs[3] at its REAL size: the surrogates inference_2d_jellyfish.py builds with --surrogate_dim 64 (dim 64,
+    mults (1,2,4,8)) on 128 x 128 images, B = 16 trajectories x 20 frames = 320 images per design-gradient call -- the size
+    bench.py's j128 leg times.  Reference: torch autograd through the stock modules (tests/torch_force_fn.py), trajectory by
+    trajectory (they are independent).  Then the same call with the tensor-size cap lowered so that the batch runs as three chunks
+    (the > 2 GB path of HipDesignGradient.__call__), and the standalone boundary-updater forward update_bd uses
+    (/root/reference/diffusion/diffusion_2d_jellyfish.py:849-866)."""
+    from diffphycon_amd.model import surrogates_2d as S2
+    from diffphycon_amd.model import surrogates_hip as SH
+    torch.manual_seed(5)
+    fm = S2.ForceUnet(dim=64, out_dim=1, dim_mults=(1, 2, 4, 8), channels=4).to(dev).eval()
+    bd = S2.Unet(dim=64, out_dim=3, dim_mults=(1, 2, 4, 8), channels=3).to(dev).eval()
+    for q in list(fm.parameters()) + list(bd.parameters()):
+        q.requires_grad_(False)
+    args = argparse.Namespace(only_vis_pressure=False, device=dev, reg_ratio=0.3, p_min=-1.7, p_max=2.3, image_size=128)
+    B, T, HW = 16, 20, 128
+    x = torch.rand(B, T, 4, HW, HW, device=dev) * 2 - 1
+    x[:, :, 3] = (torch.rand(B, T, 1, 1, device=dev) * 0.8).expand(-1, -1, HW, HW)      # theta maps are constant per frame
+    bd0e = (torch.rand(B, 1, 3, HW, HW, device=dev) > 0.7).float().expand(-1, T, -1, -1, -1).contiguous()
+    ref_s, ref_t = [], []
+    for b in range(0, B, 2):
+        gs, gt = force_fn(x[b:b + 2].clone(), bd0e[b:b + 2], fm, bd, args)
+        ref_s.append(gs[:, :, 2].detach())
+        ref_t.append(gt.detach())
+        del gs, gt
+    ref_s, ref_t = torch.cat(ref_s), torch.cat(ref_t)
+    design = SH.HipDesignGradient(fm, bd, args)
+    got = design(x, bd0e)
+    assert got.shape == x.shape and (got[:, :, :2] == 0).all()
+    assert rel(got[:, :, 2], ref_s) < 1e-4
+    assert rel(got[:, :, 3], ref_t) < 1e-4
+    # every trajectory on its own scale: the worst trajectory, relative to ITS gradient's max
+    for b in range(B):
+        assert rel(got[b, :, 2], ref_s[b]) < 2e-4 and rel(got[b, :, 3], ref_t[b]) < 2e-4, b
+    chunked = SH.HipDesignGradient(design.force, design.unet, args)
+    chunked._MAX_TENSOR_BYTES = 6 * T * HW * HW * 64 * 4 + 1           # six trajectories per chunk: 6 + 6 + 4
+    got_c = chunked(x, bd0e)
+    assert rel(got_c[:, :, 2], ref_s) < 1e-4 and rel(got_c[:, :, 3], ref_t) < 1e-4
+    th = torch.rand(B * T, device=dev)
+    imgs = bd0e.reshape(-1, 3, HW, HW)
+    with torch.no_grad():
+        ref = torch.cat([bd(imgs[i:i + 64], th[i:i + 64]) for i in range(0, B * T, 64)])
+    assert rel(design.unet(imgs, th), ref) < 2e-5
+    del ref, ref_s, ref_t, got, got_c
+    torch.cuda.empty_cache()
 
 
 def test_force_unet_head_width_mismatch_is_an_error_not_a_fault(dev):

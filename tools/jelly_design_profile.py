@@ -1,7 +1,7 @@
 import sys, os, torch, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/inference')
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/inference'); sys.path.insert(0, '/root/repo/tests')
 import inference_2d_jellyfish as J
-from diffphycon_amd.diffusion.diffusion_2d_jellyfish import force_fn
+from torch_force_fn import force_fn
 args = J.build_parser().parse_args(["--synthetic", "True", "--batch_size", "16", "--timesteps", "8", "--sampling_timesteps", "8",
                                     "--inference_result_path", "/tmp/jelly_out"])
 args.device = torch.device("cuda", 0); torch.cuda.set_device(0); torch.manual_seed(0)

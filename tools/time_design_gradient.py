@@ -12,6 +12,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))       # torch_force_fn: the torch-autograd reference lives with the tests
 from diffphycon_amd import _lib  # noqa: E402
 from diffphycon_amd.diffusion import diffusion_2d_jellyfish as DJ  # noqa: E402
 from diffphycon_amd.model import surrogates_2d as S2  # noqa: E402
@@ -53,7 +54,7 @@ ms_fwd, _ = timed(lambda: design.unet(bd0e.reshape(-1, 3, HW, HW), th), 5)
 print(f"boundary updater forward alone: {ms_fwd:.1f} ms")
 if "--no-torch" not in sys.argv:
     def torch_design():
-        gs, gt = DJ.force_fn(x.clone(), bd0e, fm, bd, args)
+        gs, gt = force_fn(x.clone(), bd0e, fm, bd, args)
         return torch.cat([gs, gt.unsqueeze(2)], dim=2)
     ms_t, g_t = timed(torch_design, 3)
     err = [((g_hip[:, :, c] - g_t[:, :, c]).abs().max() / g_t[:, :, c].abs().max()).item() for c in (2, 3)]
