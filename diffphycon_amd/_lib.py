@@ -94,6 +94,7 @@ _SIGNATURES = {
     "dpc_unet2d_modes": (C.c_char_p, [_P]),
     "dpc_unet3d_set_range_check": (C.c_int, [_P, _I]),
     "dpc_unet3d_range_status": (C.c_int, [_P, _I, _P]),
+    "dpc_train_range_status": (C.c_int, [_I, _P]),
     "dpc_profile_begin": (C.c_int, []),
     "dpc_profile_begin_classes": (C.c_int, [C.c_char_p]),
     "dpc_profile_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
@@ -162,7 +163,7 @@ _SIGNATURES = {
     "dpc_reduce_workspace_bytes": (_Z, []),
     "dpc_mse_loss_grad": (C.c_int, [_P, _P, _P, _P, _L, C.c_float, _P, _Z, _P]),
     "dpc_l2_norm": (C.c_int, [_P, _L, C.c_float, _P, _P, _Z, _P]),
-    "dpc_adam_ema_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I, _I,
+    "dpc_adam_ema_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _P, C.c_float, C.c_float, _D, _D, _D, _D, _I, _I,
                                     C.c_float, _P]),
     "dpc_burgers_fd": (C.c_int, [_P, _P, _P, _I, _I, _I, _D, _D, _D, _P]),
     "dpc_unet2d_create": (C.c_int, [C.POINTER(Unet2DCfg), C.POINTER(_P)]),

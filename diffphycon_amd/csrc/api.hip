@@ -1,5 +1,9 @@
 // extern "C" surface of libdpc (see include/dpc.h): error plumbing and the operator-level entry points.
+#include <map>
 #include <memory>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 #include "common.h"
 
@@ -64,6 +68,41 @@ int debug_switch(const char* name, int dflt) {
     if (!on) return dflt;
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+}
+// Library-internal scratch keyed by (slot, device, stream): work enqueued on ONE stream is ordered, so two launches that share a
+// buffer of this table can never overlap; different streams (DPC_TWO_STREAMS, a multi-threaded C-ABI user) get different buffers.
+// Grown geometrically under a mutex; a superseded allocation stays alive in `old` (a captured HIP graph may still replay kernels
+// that hold its address) and is released with the process.
+static thread_local void* g_scratch_base = nullptr;
+static thread_local size_t g_scratch_bytes = 0;
+ScratchScope::ScratchScope(void* base, size_t bytes) : prev_base_(g_scratch_base), prev_bytes_(g_scratch_bytes) {
+    g_scratch_base = base;
+    g_scratch_bytes = base ? bytes : 0;
+}
+ScratchScope::~ScratchScope() { g_scratch_base = prev_base_; g_scratch_bytes = prev_bytes_; }
+int stream_scratch(int slot, hipStream_t s, size_t bytes, float** out) {
+    if (g_scratch_base && bytes <= g_scratch_bytes) {        // a U-Net forward lent a region of ITS workspace (graph-capture safe)
+        *out = static_cast<float*>(g_scratch_base);
+        return DPC_OK;
+    }
+    struct Entry { void* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, hipStream_t>, Entry> table;
+    static std::vector<void*> old;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    Entry& e = table[std::make_tuple(slot, dev, s)];
+    if (bytes > e.cap) {
+        const size_t want = std::max(bytes, 2 * e.cap);
+        void* fresh = nullptr;
+        DPC_HIP(hipMalloc(&fresh, want));
+        if (e.p) old.push_back(e.p);
+        e.p = fresh;
+        e.cap = want;
+    }
+    *out = static_cast<float*>(e.p);
+    return DPC_OK;
 }
 int conv_mode_default() { return modes_current().conv; }
 int igemm_mode_default() { return modes_current().igemm; }

@@ -114,6 +114,20 @@ struct OverflowScope {
 // cannot change which kernels run (the arithmetic modes DPC_*_MODE are the documented, per-handle-captured setting and are not
 // gated).  Switches that make a kernel skip work (DPC_CONV_DBG) exist only in builds with -DDPC_ENABLE_CONV_DBG.
 int debug_switch(const char* name, int dflt);
+// library-internal scratch buffer of at least `bytes` for (slot, current device, stream) -- api.hip; slots:
+enum { SCRATCH_SMALL_ACT = 0, SCRATCH_SPLITK = 1 };
+int stream_scratch(int slot, hipStream_t s, size_t bytes, float** out);
+// A U-Net forward lends a region of its caller-provided workspace for the duration of the traversal: requests that fit are served
+// from it (per handle / per call, nothing shared between handles or streams, and no allocation under a HIP-graph capture); the
+// consumers of one region are launches of ONE stream whose uses do not overlap (the activated time embedding is consumed by the
+// launch right behind it, split-K partials by their reduce kernel).  Larger requests and the operator-level C-ABI entry points fall
+// back to the (slot, device, stream) table.
+struct ScratchScope {
+    ScratchScope(void* base, size_t bytes);
+    ~ScratchScope();
+    void* prev_base_;
+    size_t prev_bytes_;
+};
 const char* mode_name(int mode);
 std::string modes_string(const Modes& m);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -185,6 +199,10 @@ struct IgemmParams {
 // dpc_unet*_finalize reads it (a host sync, at load time only) and fails loudly instead of computing with a clamped weight.
 int* f16x3_weight_overflow_flag();          // device pointer
 int f16x3_weight_overflow_check(const char* who);   // DPC_OK, or DPC_ERR_STATE (and resets the flag)
+// f16x3 weight-gradient kernel (wgrad3.hip): device word raised when an operand leaves the fp16 window after its pre-scale (the value
+// is clamped); dpc_train_range_status reads it (one host sync; the Trainer asks when it logs the loss, never per step)
+int* f16x3_grad_overflow_flag();
+int f16x3_grad_overflow_status(int reset, hipStream_t s);
 int igemm_npad(int N);
 int igemm_kchunks(int K);
 int launch_igemm(const IgemmParams& p, hipStream_t s);

@@ -577,19 +577,9 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
         DPC_REQUIRE(!p.gn_raw || (p.out_mode == 0 && !wide && p.N % 4 == 0 && p.gn_rows % 128 == 0),
                     "igemm3: fused GroupNorm residual needs out_mode 0, N % 4 == 0, rows per sample % 128 == 0");
         if (nsl > 1) {
-            static float* scratch_d[64] = {};                           // per device (one process may drive several GPUs)
-            static size_t cap_d[64] = {};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            dev &= 63;
-            const size_t need = (size_t)nsl * p.M * p.N * sizeof(float);
-            if (need > cap_d[dev]) {
-                // grown geometrically and NEVER freed: a captured HIP graph (Burgers sampler) may still hold the old pointer
-                const size_t want = std::max(need, 2 * cap_d[dev]);
-                DPC_HIP(hipMalloc(&scratch_d[dev], want));
-                cap_d[dev] = want;
-            }
-            float* scratch = scratch_d[dev];
+            // partial sums: scratch per (device, stream), grown on first use (warm-up), never inside a steady-state step
+            float* scratch = nullptr;
+            if (int rc = stream_scratch(SCRATCH_SPLITK, s, (size_t)nsl * p.M * p.N * sizeof(float), &scratch)) return rc;
             IgemmParams q = p;
             q.ksplit = nsl;
             q.part = scratch;

@@ -107,22 +107,13 @@ int launch_small_linear_multi(const float* in, const SmallLinearBatch& d, int B,
     for (int i = 0; i < d.count; ++i) { nmax = std::max(nmax, d.N[i]); nsum += d.N[i]; }
     ProfScope prof(PROF_SMALL, 2.0 * B * nsum * K, 4.0 * (nsum * K + (double)B * (nsum + K)), s);
     if (in_act != 0) {
-        // per-device scratch, grown geometrically and never freed (a captured HIP graph may hold the pointer)
-        static float* scratch[64] = {};
-        static size_t cap[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev &= 63;
-        const size_t need = (size_t)B * K * sizeof(float);
-        if (need > cap[dev]) {
-            const size_t want = std::max(need, 2 * cap[dev]);
-            DPC_HIP(hipMalloc(&scratch[dev], want));
-            cap[dev] = want;
-        }
+        // scratch per (device, stream): two forwards on different streams never share it (api.hip: stream_scratch)
+        float* act = nullptr;
+        if (int rc = stream_scratch(SCRATCH_SMALL_ACT, s, (size_t)B * K * sizeof(float), &act)) return rc;
         const long long n = (long long)B * K;
-        hipLaunchKernelGGL(small_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, scratch[dev], n, in_act);
+        hipLaunchKernelGGL(small_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, act, n, in_act);
         DPC_LAUNCH_CHECK();
-        in = scratch[dev];
+        in = act;
         in_act = 0;
     }
     const int bb = B >= 64 ? 16 : 1;

@@ -673,21 +673,23 @@ __global__ void reduce_final_kernel(const double* __restrict__ part, int n, doub
 // torch.optim.Adam's update (lerp / addcmul / addcdiv association, eps 1e-8, bias corrections passed by value), then the EMA of
 // ema-pytorch 0.7.3 (ema_mode 0 skip | 1 copy | 2 lerp | 3 copy then lerp, weight ema_w).  g is read as g * ginv (the inverse of
 // the loss scale, a power of two) before clipping.
+// The scalars arrive as torch forms them: 1 - beta, lr / (1 - beta1^step) and sqrt(1 - beta2^step) are evaluated in DOUBLE on the host
+// (Python floats in torch.optim.adam._single_tensor_adam) and rounded to fp32 once, when they meet the fp32 tensors.
 __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, float* __restrict__ ema, long long n,
-                                                      const float* __restrict__ total_norm, float max_norm, float ginv, float lr,
-                                                      float beta1, float beta2, float eps, float bc1, float sqrt_bc2, int ema_mode,
+                                                      const float* __restrict__ total_norm, float max_norm, float ginv, float step_size,
+                                                      float omb1, float beta2, float omb2, float eps, float sqrt_bc2, int ema_mode,
                                                       float ema_w) {
     float coef = 1.f;
     if (total_norm && max_norm > 0.f) coef = fminf(max_norm / (total_norm[0] + 1e-6f), 1.0f);
-    const float step_size = lr / bc1;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = (g[i] * ginv) * coef;
         float mi = m[i], vi = v[i], wi = w[i];
-        mi = mi + (1.f - beta1) * (gi - mi);                       // exp_avg.lerp_(grad, 1 - beta1)
-        vi = vi * beta2 + ((1.f - beta2) * gi) * gi;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-        wi = wi + (-step_size * mi) / denom;                       // param.addcdiv_(exp_avg, denom, value = -step_size)
+        mi = mi + omb1 * (gi - mi);                                // exp_avg.lerp_(grad, 1 - beta1)         (weight < 0.5 branch of lerp)
+        vi = vi * beta2 + (omb2 * gi) * gi;                        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2):  a + alpha * b * c
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;            // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+        wi = wi + (-step_size * mi) / denom;                       // param.addcdiv_(exp_avg, denom, value = -step_size): a + alpha * b / c,
+                                                                   // the CPU kernel's association (the fixtures' reference run)
         m[i] = mi; v[i] = vi; w[i] = wi;
         if (ema_mode) {
             float e = ema[i];
@@ -746,6 +748,8 @@ static inline unsigned grid1d(long long total) { return (unsigned)std::min<long 
 using namespace dpc;
 
 extern "C" {
+
+int dpc_train_range_status(int reset, dpc_stream_t stream) { return f16x3_grad_overflow_status(reset, (hipStream_t)stream); }
 
 size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows) {
     const int fpr = (kw * C + 31) / 32;
@@ -835,6 +839,7 @@ int dpc_attention_bwd_seq(const float* qkv, const float* dout, float* dqkv, floa
     if (L <= 32 && use_mfma) {
         // one wave per (sequence, head); waves-per-head partial slots for the bias gradient (<= 512 as the workspace is sized)
         long long waves = std::min<long long>((n_seq * heads + 3) / 4 * 4, 256 * 4);
+        waves = std::min<long long>(waves, 512ll * heads);                               // (the workspace holds 512 slots per head)
         waves = std::max<long long>(heads * 4, waves / (heads * 4) * (heads * 4));       // multiple of 4 (workgroup) and of heads
         TattnBwdMParams q{};
         q.b.qkv = qkv; q.b.dout = dout; q.b.dqkv = dqkv; q.b.heads = heads; q.b.L = L;
@@ -952,15 +957,16 @@ int dpc_small_linear_bwd(const float* dy, const float* x, const float* W, float*
 }
 
 int dpc_adam_ema_step(float* w, const float* g, float* m, float* v, float* ema, int64_t n, const float* total_norm, float max_norm,
-                      float grad_inv_scale, float lr, float beta1, float beta2, float eps, int step, int ema_mode, float ema_weight,
+                      float grad_inv_scale, double lr, double beta1, double beta2, double eps, int step, int ema_mode, float ema_weight,
                       dpc_stream_t stream) {
     DPC_REQUIRE(w && g && m && v && n >= 1 && step >= 1, "adam_ema_step: bad argument");
     DPC_REQUIRE(ema_mode >= 0 && ema_mode <= 3 && (ema_mode == 0 || ema), "adam_ema_step: bad ema mode");
     hipStream_t s = (hipStream_t)stream;
-    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
     ProfScope prof(PROF_TRAIN_MISC, 0, (ema_mode ? 36.0 : 28.0) * (double)n, s);
     hipLaunchKernelGGL(adam_ema_kernel, dim3(grid1d(n)), dim3(256), 0, s, w, g, m, v, ema, (long long)n, total_norm, max_norm, grad_inv_scale,
-                       lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), ema_mode, ema_weight);
+                       (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)std::sqrt(bc2), ema_mode,
+                       ema_weight);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

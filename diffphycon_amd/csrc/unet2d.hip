@@ -248,6 +248,12 @@ struct Runner2D {
         float* sinemb = ar.allocf((long long)mb * dim);
         float* t1 = ar.allocf((long long)mb * dim * 4);
         temb = ar.allocf((long long)mb * dim * 4);
+        // library scratch of this forward (common.h: ScratchScope): SiLU(temb) of the one-launch time projections, then the split-K
+        // partials of the deep levels (4 slices x rows x channels: rows x channels halves per level and the reductions long
+        // enough to split -- >= 128 iterations of 32 channels -- start at level 2, i.e. <= one level-0 activation; twice that is lent)
+        const size_t scratch_bytes = std::max((size_t)mb * dim * 4, (size_t)P0 * dim * 2) * sizeof(float);
+        void* scratch_mem = ar.alloc(scratch_bytes);
+        ScratchScope scratch_scope(dry() ? nullptr : scratch_mem, scratch_bytes);
         RUN(launch_sinusoidal(t_in, h->t_freq.f(), sinemb, mb, dim / 2, s));
         RUN(launch_small_linear(sinemb, raw("time_mlp.1.weight"), raw("time_mlp.1.bias"), t1, mb, dim, dim * 4, 0, 2, s));
         RUN(launch_small_linear(t1, raw("time_mlp.3.weight"), raw("time_mlp.3.bias"), temb, mb, dim * 4, dim * 4, 0, 0, s));

@@ -507,6 +507,10 @@ struct Runner {
         float* sinemb = ar.allocf((long long)mb * dim);
         float* t1 = ar.allocf((long long)mb * dim * 4);
         temb = ar.allocf((long long)mb * dim * 4);
+        // library scratch of this forward (common.h: ScratchScope): SiLU(temb) of the one-launch time projections
+        const size_t scratch_bytes = (size_t)mb * dim * 4 * sizeof(float);
+        void* scratch_mem = ar.alloc(scratch_bytes);
+        ScratchScope scratch_scope(dry() ? nullptr : scratch_mem, scratch_bytes);
         RUN(launch_sinusoidal(t_in, h->t_freq.f(), sinemb, mb, dim / 2, s));
         RUN(launch_small_linear(sinemb, raw("time_mlp.1.weight"), raw("time_mlp.1.bias"), t1, mb, dim, dim * 4, 0, 2, s));
         RUN(launch_small_linear(t1, raw("time_mlp.3.weight"), raw("time_mlp.3.bias"), temb, mb, dim * 4, dim * 4, 0, 0, s));

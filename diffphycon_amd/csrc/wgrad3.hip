@@ -37,7 +37,11 @@ struct Wgrad3Params {
     int nslab;
     long long planes;          // B * F
     float x_scale, dy_scale;
+    int* oflag;                // gradient-range sentinel (f16x3_grad_overflow_flag): bit 0 = an activation, bit 1 = an output gradient left the
+                               // fp16 window after its pre-scale (it was clamped), or was not finite
 };
+
+constexpr unsigned F16_MAX_BITS = 0x477FE000u;          // 65504.0f: |bits| above it (Inf / NaN included) do not fit an fp16 operand
 
 template <int W>
 struct Wg3Cfg {
@@ -115,7 +119,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
                 const int q = tid + 256 * u, pt = q >> 3, c4 = q & 7;
                 const int r = pt / W, w = pt % W;
                 const int slot = (G * RPI + r) & (NS - 1);
-                const f32x4 v = xr[d][u] * p.x_scale;
+                f32x4 v = xr[d][u] * p.x_scale;
+                if (max(max(abs_bits(v[0]), abs_bits(v[1])), max(abs_bits(v[2]), abs_bits(v[3]))) > F16_MAX_BITS) atomicOr(p.oflag, 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = h3::sat16(v[e]);
                 uint2 hi, lo;
                 hi.x = h3::cvt_pk(v[0], v[1]); hi.y = h3::cvt_pk(v[2], v[3]);
                 lo.x = f16_sub_pk(v[0], v[1], hi.x); lo.y = f16_sub_pk(v[2], v[3], hi.y);
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
         for (int u = 0; u < 4; ++u) {
             const int q = tid + 256 * u, pt = q >> 4, c4 = q & 15;
             f32x4 v = yr[u] * p.dy_scale;
+            if (max(max(abs_bits(v[0]), abs_bits(v[1])), max(abs_bits(v[2]), abs_bits(v[3]))) > F16_MAX_BITS) atomicOr(p.oflag, 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = h3::sat16(v[e]);
             uint2 hi, lo;
@@ -276,6 +284,27 @@ static int launch_w(const Wgrad3Params& p, int nblocks, hipStream_t s) {
     return DPC_OK;
 }
 
+static int* g_grad_flag = nullptr;
+int* f16x3_grad_overflow_flag() {
+    if (!g_grad_flag) {
+        if (hipMalloc(&g_grad_flag, sizeof(int)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_grad_flag, 0, sizeof(int));
+    }
+    return g_grad_flag;
+}
+int f16x3_grad_overflow_status(int reset, hipStream_t s) {
+    if (!g_grad_flag) return DPC_OK;
+    int v = 0;
+    DPC_HIP(hipMemcpyAsync(&v, g_grad_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPC_HIP(hipStreamSynchronize(s));
+    if (!v) return DPC_OK;
+    if (reset) DPC_HIP(hipMemsetAsync(g_grad_flag, 0, sizeof(int), s));
+    return fail(DPC_ERR_STATE, std::string("f16x3 weight gradient: ") + ((v & 1) ? "an activation exceeded |x| = 4094" : "") +
+                               ((v & 3) == 3 ? " and " : "") + ((v & 2) ? "an output gradient exceeded 65504 / f16_dy_scale" : "") +
+                               " (or was not finite) since the last check: the operand was clamped, the step's gradients are not exact; "
+                               "lower the loss scale or use wgrad_mode='f32'");
+}
+
 int launch_wgrad3(const float* x, const float* dy, float* dw, int B, int F, int H, int W, int C, int N, int ctot, int coff, float x_scale,
                   float dy_scale, float out_scale, int accumulate, void* ws, hipStream_t s) {
     Wgrad3Params p{};
@@ -286,6 +315,8 @@ int launch_wgrad3(const float* x, const float* dy, float* dw, int B, int F, int 
     p.nslab = wgrad3_slabs(nunits, p.planes);
     p.part = reinterpret_cast<float*>(align_up((size_t)ws, 256));
     p.x_scale = x_scale; p.dy_scale = dy_scale;
+    p.oflag = f16x3_grad_overflow_flag();
+    DPC_REQUIRE(p.oflag, "wgrad3: cannot allocate the gradient-range sentinel word");
     const int nblocks = nunits * p.nslab;                                  // nslab % 8 == 0: 8 XCD lanes of nunits * nslab / 8 blocks
     {
         ProfScope prof(PROF_WGRAD3, 2.0 * (double)p.planes * H * W * 27 * C * N, 0, s);

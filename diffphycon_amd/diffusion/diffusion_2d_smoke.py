@@ -426,6 +426,8 @@ class Trainer(object):
         self.ema_sched = _EmaSchedule(beta=ema_decay, update_every=ema_update_every)
         self._data = data
         self._t = None                  # TrainableUnet3D, built on first use (the checkpoint reader needs none of this)
+        self._pending = None            # (opt, ema) of a checkpoint read before the training buffers existed
+        self.resume, self.resume_step = resume, resume_step      # stored like the reference (:909-910), whose resume branch is commented out (:929-931)
         self.losses = []
 
     @property
@@ -433,30 +435,79 @@ class Trainer(object):
         return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
     # ------------------------------------------------------------------ checkpoints (:942-985)
+    def _param_order(self):
+        """(flat-buffer key, shape) in the order of `diffusion_model.parameters()` -- the index space of torch.optim.Adam's
+        state_dict (:912: Adam(diffusion_model.parameters())); the denoiser is the diffusion's only parameterised child."""
+        return [(k, tuple(p.shape)) for k, p in self.model.model.named_parameters()]
+
     def load(self, milestone):
+        """(:957-985) model weights, step, optimizer state and EMA.  `opt` is torch.optim.Adam's state_dict ({'state': {i: {'step',
+        'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}, i = position in diffusion_model.parameters()), `ema` is the EMA module's
+        state_dict ('initted', 'step', 'ema_model.model.<name>', ...).  The optimizer / EMA state is applied as soon as the
+        training buffers exist: now if they do, otherwise when `train()` / `train_step()` first builds them -- so the usual order
+        Trainer(...); load(); train() resumes the moments, the schedule position and the average.  An `opt` in another layout is an error."""
         path = str(self.results_path / f"model-{milestone}.pt")
         data = torch.load(path, map_location="cpu")
         sd = {k: v for k, v in data["model"].items() if not k.endswith("rotary_emb.freqs")}
         self.model.load_state_dict(sd)
         self.step = data.get("step", 0)
-        opt = data.get("opt")
+        opt, ema = data.get("opt"), data.get("ema")
+        if opt is not None and not (isinstance(opt, dict) and "state" in opt and "param_groups" in opt):
+            raise ValueError(f"{path}: 'opt' is not a torch.optim.Adam state_dict (keys {sorted(opt) if isinstance(opt, dict) else type(opt)})")
+        self._pending = (opt, ema)
         if self._t is not None:
             self._after_weight_change(reload=True)
-            if isinstance(opt, dict) and "exp_avg" in opt:
-                self.m.copy_(opt["exp_avg"].to(self.m.device))
-                self.v.copy_(opt["exp_avg_sq"].to(self.v.device))
-                self.opt_step = int(opt["step"])
-        self._loaded_opt = opt
+            self._apply_pending()
+
+    def _apply_pending(self):
+        """Copy a loaded optimizer / EMA state into the flat training buffers (called once they exist)."""
+        opt, ema = getattr(self, "_pending", None) or (None, None)
+        self._pending = None
+        T = self._t
+        order = self._param_order()
+        if opt is not None and opt["state"]:
+            if len(opt["state"]) != len(order):
+                raise ValueError(f"checkpoint optimizer state holds {len(opt['state'])} parameters, the denoiser has {len(order)}")
+            steps = set()
+            for i, (k, shape) in enumerate(order):
+                st = opt["state"][i]
+                if tuple(st["exp_avg"].shape) != shape:
+                    raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {k} has {shape}")
+                o, n = T.offsets[k], T.ctx.W[k].numel()
+                self.m[o:o + n].copy_(st["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
+                self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
+                steps.add(int(st["step"]))
+            if len(steps) != 1:
+                raise ValueError(f"optimizer state carries different step counts per parameter: {sorted(steps)}")
+            self.opt_step = steps.pop()              # Adam's bias correction AND MultiStepLR's position (one scheduler step per optimizer step)
+        if ema is not None:
+            for k, _ in order:
+                o, n = T.offsets[k], T.ctx.W[k].numel()
+                self.ema[o:o + n].copy_(ema["ema_model.model." + k].reshape(-1).to(self.ema.device, torch.float32))
+            self.ema_sched.step, self.ema_sched.initted = int(ema["step"]), bool(ema["initted"])
+        else:
+            self.ema.copy_(T.w)                      # no average in the file: EMA(model) starts as a copy of the loaded weights (:920)
 
     def save(self, milestone):
+        """(:942-955) {'step', 'model', 'opt', 'ema', 'scaler'} with `opt` / `ema` in the layouts `load` documents."""
         self.results_path.mkdir(exist_ok=True, parents=True)
         opt = ema = None
         if self._t is not None:
-            opt = {"step": self.opt_step, "exp_avg": self.m.cpu(), "exp_avg_sq": self.v.cpu(), "lr": self._lr(), "betas": self.adam_betas,
-                   "layout": dict(self._t.offsets)}
-            ema = {"ema_model.model." + k: self.ema[o:o + self._t.ctx.W[k].numel()].view(self._t.ctx.W[k].shape).cpu()
-                   for k, o in self._t.offsets.items()}
-            ema["initted"], ema["step"] = torch.tensor(self.ema_sched.initted), torch.tensor(self.ema_sched.step)
+            T, order = self._t, self._param_order()
+
+            def views(flat):
+                return {k: flat[T.offsets[k]:T.offsets[k] + T.ctx.W[k].numel()].view(shape).cpu().clone() for k, shape in order}
+            m, v = views(self.m), views(self.v)
+            opt = {"state": {i: {"step": torch.tensor(float(self.opt_step)), "exp_avg": m[k], "exp_avg_sq": v[k]}
+                             for i, (k, _) in enumerate(order)} if self.opt_step > 0 else {},
+                   "param_groups": [{"lr": self._lr(), "betas": self.adam_betas, "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                                     "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                                     "initial_lr": self.train_lr, "params": list(range(len(order)))}]}
+            online = self.model.state_dict()
+            ema = {"initted": torch.tensor(self.ema_sched.initted), "step": torch.tensor(self.ema_sched.step)}
+            ema.update({"online_model." + k: t.detach().cpu().clone() for k, t in online.items()})
+            ema.update({"ema_model." + k: t.detach().cpu().clone() for k, t in online.items()})      # buffers: equal on both copies
+            ema.update({"ema_model.model." + k: t for k, t in views(self.ema).items()})
         data = {"step": self.step, "model": self.model.state_dict(), "opt": opt, "ema": ema, "scaler": None}
         torch.save(data, str(self.results_path / f"model-{milestone}.pt"))
 
@@ -476,6 +527,8 @@ class Trainer(object):
         self.norm = torch.zeros(1, device=dev)
         self.opt_step = 0
         self._acc = torch.zeros_like(T.g) if self.gradient_accumulate_every > 1 else None
+        if getattr(self, "_pending", None) is not None:          # load() came first: resume moments, schedule position and average
+            self._apply_pending()
         return T
 
     def _after_weight_change(self, reload=False):
@@ -523,6 +576,11 @@ class Trainer(object):
                                        self.adam_betas[1], 1e-8, self.opt_step, mode, wgt, _lib.stream()))
         self._after_weight_change()
 
+    def check_gradient_range(self):
+        """The f16x3 weight-gradient sentinel (include/dpc.h: dpc_train_range_status): raises when an operand of a weight-gradient
+        launch since the last call was clamped at the fp16 limit or was not finite.  ONE host sync: called where train() syncs anyway."""
+        _lib.check(_lib.lib().dpc_train_range_status(1, _lib.stream()))
+
     def train_step(self, batches):
         """One iteration of Trainer.train's while loop (:1011-1051) given `gradient_accumulate_every` batches."""
         T = self._ensure()
@@ -569,9 +627,12 @@ class Trainer(object):
             loss = self.train_step(batches)
             if self.step % log_every == 0:
                 self.losses.append((self.step, float(loss.item())))
+                self.check_gradient_range()
                 if parallel.rank() == 0:
                     print(f"step: {self.step}, loss: {self.losses[-1][1]:.4f}, LR: {self._lr()}", flush=True)
-            if self.step % self.save_and_sample_every == 0 and parallel.rank() == 0:
-                self.save(self.step // self.save_and_sample_every)
+            if self.step % self.save_and_sample_every == 0:
+                self.check_gradient_range()          # never checkpoint weights that came from clamped gradients
+                if parallel.rank() == 0:
+                    self.save(self.step // self.save_and_sample_every)
         if parallel.rank() == 0:
             print("training complete")

@@ -12,7 +12,11 @@ launch / one collective over the flat buffers.
 Activations are channels-last fp32 [B F H W, C].  Arithmetic: forward GEMM-shaped ops in the library's default mode (f16x3);
 backward-DATA convolutions are the forward operators on flipped / transposed weights in `bwd_mode` -- "x6" (default: exact fp32
 products on the bf16 matrix cores; gradients span 1e-9 .. 1e-2 and need no range management) or "f16x3" with a power-of-two loss
-scale (`loss_scale`, undone in the optimizer kernel); WEIGHT gradients are exact fp32 products (native fp32 MFMA) in either case.
+scale (`loss_scale`, undone in the optimizer kernel).  WEIGHT gradients: `wgrad_mode` "f16x3" (default) runs the 3x3x3 convolutions'
+weight gradients -- 95 % of the weight-gradient flop -- on the fp16 matrix cores from 22-bit split operands (x * 2^4, dy * 2^24 /
+loss_scale, both SATURATING at 65504: |x| <= 4094, |d loss / d conv output| <= 3.9e-3 * loss_scale; csrc/wgrad3.hip raises a device
+word when it clamps, `Trainer.check_gradient_range()` / dpc_train_range_status read it), every other geometry -- and every
+geometry under wgrad_mode "f32" -- uses exact fp32 products on the native fp32 MFMA.
 """
 import ctypes as C
 import math

@@ -25,9 +25,17 @@ def init_process_group(rank, world_size, device):
         dist.init_process_group(backend, rank=rank, world_size=world_size)
 
 
-def gather_metric_rows(rows):
+def _no_exchange(force):
+    """True when a helper may skip its collective: no process group, or a group of one (unless `force`: tests/test_gpu_rccl.py runs
+    the real collectives through RCCL on the one GPU a test box has)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and not force
+
+
+def gather_metric_rows(rows, force=False):
     """rows: [B_local, M] per rank (B_local may differ) -> [B_global, M] on every rank, in global trajectory order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_exchange(force):
         return rows
     if dist.get_backend() == "gloo" and rows.is_cuda:          # gloo gathers host tensors
         return gather_metric_rows(rows.cpu()).to(rows.device)
@@ -63,13 +71,13 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
-def allreduce_sum_(flat):
+def allreduce_sum_(flat, force=False):
     """SUM of the flat gradient buffer over the ranks, in place; returns the world size (the caller folds the 1 / world of DDP's
     gradient averaging into the optimizer kernel's scale).  The training step's only collective (Trainer.train :1025: accelerate's
     DDP all-reduce in the reference): ONE call on ONE contiguous buffer (~92 MB at dim 64, (1, 2, 4)) -- a single large ring
     all-reduce is what the point-to-point xGMI links want, instead of DDP's 25 MB buckets.  Every rank receives the same bits,
     so the optimizer keeps the replicas bit-identical."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_exchange(force):
         return 1
     if dist.get_backend() == "gloo" and flat.is_cuda:          # gloo reduces host tensors (several ranks on ONE GPU in the tests)
         h = flat.cpu()

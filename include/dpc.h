@@ -314,7 +314,12 @@ int dpc_stem_run(dpc_stem_t h, const float* x, int x_channels_total, int x_chann
  * f16_dy_scale != 0 (a power of two): the 3x3x3 stride-1 pad-1 convolutions with W in {16, 32, 64}, C % 32 == 0, N % 64 == 0
  * run on the fp16 matrix cores instead (csrc/wgrad3.hip: LDS transpose reads, f16x3 = 22-bit split operands, 3 MFMAs per product,
  * fp32 accumulation): x is pre-scaled by 2^4 like every f16x3 activation operand, dy by f16_dy_scale (saturating at 65504), both
- * undone in the fixed-order reduction; other shapes ignore the flag.  rows of the workspace query: B * F * Ho. */
+ * undone in the fixed-order reduction; other shapes ignore the flag.  rows of the workspace query: B * F * Ho.
+ * Both operands SATURATE at the fp16 limit (|x| > 4094, |dy| > 65504 / f16_dy_scale) and a saturated (or non-finite) element raises
+ * a device word; dpc_train_range_status reads it (ONE host sync; reset != 0 clears it): DPC_OK, or DPC_ERR_STATE when any
+ * f16x3 weight-gradient launch since the last reset clamped an operand -- that step's gradients are then not exact.  The Trainer
+ * (diffusion_2d_smoke.py Trainer.train :998-1054) asks where it already syncs: when it logs the loss and before it saves. */
+int dpc_train_range_status(int reset, dpc_stream_t stream);
 size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows /* B * F * Ho */);
 int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, int Hi, int Wi, int C, int Ho, int Wo, int N, int kf,
                       int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
@@ -354,9 +359,11 @@ int dpc_l2_norm(const float* x, int64_t n, float scale, float* out, void* ws, si
 /* One optimizer step on flat fp32 buffers (Trainer.train :1027-1043): g <- g * grad_inv_scale * min(1, max_norm / (total_norm[0] +
  * 1e-6)) (total_norm NULL or max_norm <= 0: no clipping), torch.optim.Adam's update with its association (exp_avg.lerp_,
  * exp_avg_sq.mul_.addcmul_, param.addcdiv_(exp_avg, sqrt(v) / sqrt(1 - beta2^step) + eps, -lr / (1 - beta1^step))), then the EMA
- * of ema-pytorch 0.7.3 on `ema`: ema_mode 0 none | 1 copy | 2 lerp with ema_weight = 1 - decay | 3 copy then lerp. */
+ * of ema-pytorch 0.7.3 on `ema`: ema_mode 0 none | 1 copy | 2 lerp with ema_weight = 1 - decay | 3 copy then lerp.
+ * lr, beta1, beta2, eps are doubles like torch's Python floats: 1 - beta, lr / (1 - beta1^step), sqrt(1 - beta2^step) are formed in
+ * double and rounded to fp32 once (1.f - 0.99f differs from float(1 - 0.99) by 1e-5 relative). */
 int dpc_adam_ema_step(float* w, const float* g, float* m, float* v, float* ema, int64_t n, const float* total_norm, float max_norm,
-                      float grad_inv_scale, float lr, float beta1, float beta2, float eps, int step, int ema_mode, float ema_weight,
+                      float grad_inv_scale, double lr, double beta1, double beta2, double eps, int step, int ema_mode, float ema_weight,
                       dpc_stream_t stream);
 
 /* ------------------------------------------------------------------ Burgers finite-difference solver

@@ -43,6 +43,30 @@ dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert t.item() == 1.5
 assert torch.equal(parallel.gather_metric_rows(rows), rows) and parallel.max_over_ranks(0.5, dev) == 0.5
 assert parallel.allreduce_sum_(g) == 1
+# the training step's collective at its REAL size through RCCL: the flat fp32 gradient buffer of the dim-64 (1,2,4) denoiser
+# (23.0 M parameters = 92 MB), filled by a libdpc kernel on the launch stream right before the all-reduce (stream ordering between
+# the library's kernels and RCCL's), then the gradient norm on the reduced buffer -- /root/reference/diffusion/diffusion_2d_smoke.py:1025-1027
+from diffphycon_amd import _lib as L
+n = 23_012_352
+flat = torch.empty(n, device=dev)
+L.check(L.lib().dpc_philox_normal(L.ptr(flat), 1, n, 1234, 0, 0, L.stream()))
+before = flat.clone()
+assert parallel.allreduce_sum_(flat, force=True) == 1
+norm = torch.zeros(1, device=dev)
+ws = L.workspace(L.lib().dpc_reduce_workspace_bytes(), dev)
+import ctypes as C
+L.check(L.lib().dpc_l2_norm(L.ptr(flat), n, 1.0, L.ptr(norm), C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+assert torch.equal(flat, before)                              # SUM over one rank: the same bits back
+assert abs(norm.item() - before.double().norm().item()) < 1e-3 * norm.item()
+t0 = time.perf_counter()
+for _ in range(5):
+    parallel.allreduce_sum_(flat, force=True)
+torch.cuda.synchronize()
+print("allreduce 92 MB x5: %%.1f ms" %% ((time.perf_counter() - t0) * 1e3))
+# the inference scripts' one exchange: ragged per-rank metric rows (float64 [B, 5]) through two all_gathers
+mrows = torch.arange(64 * 5, dtype=torch.float64, device=dev).reshape(64, 5)
+assert torch.equal(parallel.gather_metric_rows(mrows, force=True), mrows)
+assert parallel.gather_metric_rows(mrows[:0], force=True).shape == (0, 5)
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_OK")

@@ -121,6 +121,49 @@ def test_training_step_is_bit_reproducible_and_inference_sees_the_trained_weight
     assert (sd["init_conv.weight"] - torch.from_numpy(g["w0:init_conv.weight"])).abs().max() > 1e-4      # they did move
 
 
+def test_checkpoint_resume_is_bit_identical_to_the_uninterrupted_run(dev, tmp_path):
+    """Trainer.save / load (:942-985): Trainer(...); load(); train_step() -- the usual order, training buffers built AFTER the
+    load -- continues with Adam's moments and step count, the LR-schedule position and the EMA (average, step, initted) of the
+    file: weights, moments and average after 2 + 2 steps are bit-equal to 4 uninterrupted steps.  `opt` / `ema` are written
+    in the layouts of torch.optim.Adam.state_dict() / the EMA module's state_dict()."""
+    g = load_golden("train_joint")
+
+    def run(tr, steps):
+        tr.ema_sched.update_every, tr.ema_sched.update_after_step = 1, 1      # the average must leave its copy phase inside the test
+        for step in steps:
+            k = step % 2
+            tr.loss_and_gradients(torch.from_numpy(g[f"s{k}:state"]).to(dev), torch.from_numpy(g[f"s{k}:t"]).to(dev),
+                                  torch.from_numpy(g[f"s{k}:noise"]).to(dev))
+            tr.optimizer_step()
+            tr.step += 1
+        return tr
+    full = run(_trainer(g, dev, results_path=str(tmp_path)), range(4))
+    first = run(_trainer(g, dev, results_path=str(tmp_path)), range(2))
+    first.save(7)
+    ck = torch.load(str(tmp_path / "model-7.pt"), map_location="cpu")
+    n = len(list(first.model.parameters()))
+    assert set(ck["opt"]) == {"state", "param_groups"} and len(ck["opt"]["state"]) == n and ck["opt"]["param_groups"][0]["params"] == list(range(n))
+    assert {"initted", "step", "ema_model.model.init_conv.weight", "online_model.model.init_conv.weight", "ema_model.betas"} <= set(ck["ema"])
+    resumed = _trainer(g, dev, results_path=str(tmp_path))
+    resumed.load(7)                                  # no training buffers yet: the state is applied when they are built
+    assert resumed._t is None and resumed.step == 2
+    run(resumed, range(2, 4))
+    assert resumed.opt_step == full.opt_step == 4 and resumed.ema_sched.step == full.ema_sched.step
+    for name in ("m", "v", "ema"):
+        assert torch.equal(getattr(resumed, name), getattr(full, name)), name
+    assert torch.equal(resumed._t.w, full._t.w)
+    assert not torch.equal(full.ema, full._t.w)      # (the average is a real average by now, not the copy of the first 100 steps)
+    # a trainer whose buffers already exist takes the state at once; an optimizer state in another layout is refused
+    again = run(_trainer(g, dev, results_path=str(tmp_path)), range(1))
+    again.load(7)
+    run(again, range(2, 4))
+    assert torch.equal(again._t.w, full._t.w) and torch.equal(again.ema, full.ema)
+    ck["opt"] = {"step": 2, "exp_avg": torch.zeros(3)}
+    torch.save(ck, str(tmp_path / "model-8.pt"))
+    with pytest.raises(ValueError, match="Adam state_dict"):
+        _trainer(g, dev, results_path=str(tmp_path)).load(8)
+
+
 @pytest.mark.parametrize("bwd_mode,loss_scale", [("x6", 1.0), ("f16x3", 2.0 ** 20)])
 def test_full_width_gradients_vs_autograd_on_the_oracle(bwd_mode, loss_scale, dev):
     """dim 64, mults (1, 2, 4) -- the widths train_2d_smoke.py:43-47 builds -- at 8 frames x 16 x 16, B = 2: every parameter
@@ -207,6 +250,41 @@ def test_conv_weight_gradient(case, dev):
     assert torch.all(got[:, :2] == 7.0) and torch.all(got[:, 2 + Ci:] == 7.0)      # nothing outside the slice is touched
     err = (got[:, 2:2 + Ci] - ref).abs().max().item() / ref.abs().max().item()
     assert err < 3e-6, err
+
+
+def test_f16x3_weight_gradient_saturation_is_reported(dev):
+    """the f16x3 weight-gradient kernel clamps dy * f16_dy_scale at 65504 and x * 2^4 likewise; a clamped (or non-finite)
+    operand raises the device word that dpc_train_range_status reads.  In range: status OK.  One dy element past the window, one
+    activation past 4094, one NaN: each is reported (and cleared by the read), and the clamped launch still returns finite numbers."""
+    import ctypes as C
+    from diffphycon_amd import _lib as L
+    lib = L.lib()
+    B, Fr, H, W, Ci, N = 1, 3, 16, 16, 32, 64
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B * Fr * H * W, Ci, generator=g).to(dev)
+    dy = (torch.randn(B * Fr * H * W, N, generator=g) * 1e-6).to(dev)
+    ws = L.workspace(lib.dpc_conv_wgrad_workspace_bytes(Ci, N, 3, 3, 3, B * Fr * H), dev)
+    dw = torch.empty(N, Ci, 3, 3, 3, device=dev)
+
+    def run(xx, dd):
+        L.check(lib.dpc_conv_wgrad_cl(L.ptr(xx), L.ptr(dd), L.ptr(dw), B, Fr, H, W, Ci, H, W, N, 3, 3, 3, 1, 1, 1, 1, 1, 0, Ci, 0, 1.0,
+                                      2.0 ** 20, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+        return lib.dpc_train_range_status(1, L.stream())
+    lib.dpc_train_range_status(1, L.stream())                     # clear whatever an earlier test left
+    assert run(x, dy) == 0
+    big = dy.clone()
+    big[100, 7] = 0.5                                             # 0.5 * 2^20 > 65504
+    assert run(x, big) != 0 and b"output gradient" in lib.dpc_last_error()
+    assert torch.isfinite(dw).all()
+    assert lib.dpc_train_range_status(1, L.stream()) == 0         # the read cleared it
+    xb = x.clone()
+    xb[5, 3] = 5000.0
+    assert run(xb, dy) != 0 and b"activation" in lib.dpc_last_error()
+    assert torch.isfinite(dw).all()
+    bad = dy.clone()
+    bad[0, 0] = float("nan")
+    assert run(x, bad) != 0
+    lib.dpc_train_range_status(1, L.stream())
 
 
 def test_column_reductions_and_small_linear_backward(dev):
@@ -298,5 +376,5 @@ def test_train_script_two_ranks_keep_bit_identical_replicas(tmp_path):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "replicas identical: True" in p.stdout and "training complete" in p.stdout, p.stdout[-2000:]
     ck = torch.load(os.path.join(str(tmp_path), "joint", "model-1.pt"), map_location="cpu")
-    assert ck["step"] == 3 and "model.init_conv.weight" in ck["model"] and ck["opt"]["step"] == 3
+    assert ck["step"] == 3 and "model.init_conv.weight" in ck["model"] and int(ck["opt"]["state"][0]["step"]) == 3
     assert set(ck) == {"step", "model", "opt", "ema", "scaler"}                      # Trainer.save's keys (:942-954)
