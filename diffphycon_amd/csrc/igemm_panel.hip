@@ -166,6 +166,11 @@ __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const un
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], ws[nt][PB[term]], acc[mt][nt], 0, 0, 0);
     };
     constexpr int NS = 2 * KC;                                    // k-steps (4, 8, 16: multiples of 4)
+    // A spent weight set (the MFMAs' B operand) keeps its registers until >= 4 younger MFMAs were issued (common.h: mfma_keep): a
+    // k-step issues 3 MT NT MFMAs, so the set of step st is released at the end of step st + BACK; `spent` holds the SSA values
+    // (no copies) past the ring's own re-load of the slot.
+    constexpr int BACK = 3 * MT * NT >= 4 ? 1 : 2;
+    f16x8_p spent[3][NT][2];
     lda(0, fa[0]);
 #pragma unroll
     for (int s = 0; s < NS; s += 4) {
@@ -175,9 +180,17 @@ __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const un
             if (st + 1 < NS) lda(st + 1, fa[(u + 1) & 1]);
             mma(fa[u & 1], w[u]);
             __builtin_amdgcn_sched_barrier(0);                    // (the re-load of set u+3 = u-1 stays behind this step's MFMAs)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) spent[st % 3][nt][pl] = w[u][nt][pl];
+            if (st >= BACK) mfma_keep_set<MT, NT>(acc, spent[(st - BACK) % 3]);
             if (st + 3 < NS) ldw(st + 3, w[(u + 3) & 3]);
         }
     }
+    // the last sets stay allocated to the end of the MFMA stream (nothing behind it reads LDS)
+#pragma unroll
+    for (int b = 0; b < BACK; ++b) mfma_keep_set<MT, NT>(acc, spent[(NS - 1 - b) % 3]);
 
     // ---- 3. epilogue (igemm_epilogue.h: igemm3_kernel's vector form, all residual loads in flight at once)
     const int q3 = l31 & 3;

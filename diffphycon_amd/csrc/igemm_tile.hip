@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256, 2) void igemm3t_kernel(IgemmParams p, const un
     };
     constexpr int NS = NTAPS * 2 * KCH;
     static_assert(NS % 4 == 0, "the weight ring is walked four k-steps at a time");
+    // spent weight sets (the MFMAs' B operand) keep their registers for >= 4 younger MFMAs (common.h: mfma_keep), as in igemm_panel.hip
+    constexpr int BACK = 3 * MT * NT >= 4 ? 1 : 2;
+    f16x8_t spent[3][NT][2];
     lda(0, fa[0]);
 #pragma unroll
     for (int s = 0; s < NS; s += 4) {
@@ -147,9 +150,16 @@ __global__ __launch_bounds__(256, 2) void igemm3t_kernel(IgemmParams p, const un
             if (st + 1 < NS) lda(st + 1, fa[(u + 1) & 1]);
             mma(fa[u & 1], w[u]);
             __builtin_amdgcn_sched_barrier(0);                    // (the re-load of set u+3 = u-1 stays behind this step's MFMAs: DESIGN.md 6.2)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) spent[st % 3][nt][pl] = w[u][nt][pl];
+            if (st >= BACK) mfma_keep_set<MT, NT>(acc, spent[(st - BACK) % 3]);
             if (st + 3 < NS) ldw(st + 3, w[(u + 3) & 3]);
         }
     }
+#pragma unroll
+    for (int b = 0; b < BACK; ++b) mfma_keep_set<MT, NT>(acc, spent[(NS - 1 - b) % 3]);
 
     // ---- 3. epilogue (igemm_epilogue.h)
     const int q3 = l31 & 3;

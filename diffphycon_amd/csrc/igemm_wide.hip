@@ -202,9 +202,19 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
     // overtake a queued MFMA -- DESIGN.md 6.2): the scheduling barriers pin exactly that order and leave the rest to hipcc.
     WStage s0, s1;
     auto phase = [&](int img, WStage& st, int it_next, bool trail) {
+        // (k-step 0's B fragments were multiplied LAST in the previous phase: their registers stay allocated through the twelve trailing
+        //  MFMAs below -- common.h: mfma_keep -- so this phase's k-step-0 reads land in another register set)
+        f16x8_w fb0_spent[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb0_spent[nt][pl] = fb0[nt][pl];
         read_frags(img, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (trail) mfma12(fa1, fb1);
+        if (trail) {
+            mfma12(fa1, fb1);
+            mfma_keep_set<MT, 2>(acc, fb0_spent);
+        }
         stash(st, img ^ 1);
         mfma12(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);

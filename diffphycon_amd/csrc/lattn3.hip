@@ -131,6 +131,14 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             for (int r = 0; r < 16; ++r) ctxT[hd][r] = 0.f;
         }
         if (PREFETCH && wave < ntiles) load_rows(wave);
+        // MFMA B operands that come from LDS (k / v weights) or die with their product (exp k) keep their registers until two more
+        // 3-MFMA groups were issued (common.h: mfma_keep / mfma_order_point); the last pair of a head is carried into
+        // the first two groups of the next head (and tile)
+        f16x8 es_carry[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) es_carry[i][pl] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = wave; t < ntiles; t += 8) {
             f16x8 xs[KS][2];
             if (!PREFETCH) load_rows(t);
@@ -143,13 +151,19 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 f32x16 kk, vv;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { kk[r] = 0.f; vv[r] = 0.f; }
+                f16x8 wk[KS][2], wv[KS][2];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    f16x8 w[2];
-                    load_w2(Wk, ks, loff, w);
-                    mfma3(kk, xs[ks], w);                      // K[token][d]: lane = d, regs = tokens
-                    load_w2(Wk + KS * 2048, ks, loff, w);
-                    mfma3(vv, xs[ks], w);                      // V[token][e]: lane = e, regs = tokens
+                    load_w2(Wk, ks, loff, wk[ks]);
+                    mfma3(kk, xs[ks], wk[ks]);                 // K[token][d]: lane = d, regs = tokens
+                    if (ks == 0) mfma_keep(kk, es_carry[0][0], es_carry[0][1]);
+                    else mfma_keep(kk, wk[ks - 1][0], wk[ks - 1][1]);
+                    mfma_order_point();
+                    load_w2(Wk + KS * 2048, ks, loff, wv[ks]);
+                    mfma3(vv, xs[ks], wv[ks]);                 // V[token][e]: lane = e, regs = tokens
+                    if (ks == 0) mfma_keep(vv, es_carry[1][0], es_carry[1][1]);
+                    else mfma_keep(vv, wv[ks - 1][0], wv[ks - 1][1]);
+                    mfma_order_point();
                 }
                 float tm = -INFINITY;
 #pragma unroll
@@ -177,7 +191,14 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 split_acc<true>(vv, PROJ_DESCALE * SV, vs);
                 split_acc<false>(kk, SP, es);
                 mfma3(ctxT[hd], vs[0], es[0]);                 // ctx^T[e][d]: lane = d, regs = e
+                mfma_keep(ctxT[hd], wk[KS - 1][0], wk[KS - 1][1]);
                 mfma3(ctxT[hd], vs[1], es[1]);
+                mfma_keep(ctxT[hd], wv[KS - 1][0], wv[KS - 1][1]);
+                mfma_order_point();
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) es_carry[i][pl] = es[i][pl];
             }
         }
         // ---- merge the 8 partial contexts (two heads per round through region A), normalise, write operand planes
@@ -239,6 +260,11 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
     // ================= phase 2: outputs =================
     const float qscale = 0.17677669529663687f;
     if (PREFETCH && wave < ntiles) load_rows(wave);
+    f16x8 wo_carry[2][2];                                      // (as es_carry: the last two to_out fragments of a head)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = wave; t < ntiles; t += 8) {
         f16x8 xs[KS][2];
         if (!PREFETCH) load_rows(t);
@@ -263,6 +289,7 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 f16x8 w[2];
                 load_w2(Wq, ks, loff, w);
                 mfma3(qT, w, xs[ks]);                          // Q^T[d][token]: lane = token, regs = d
+                if (ks < 2) mfma_keep(qT, wo_carry[ks][0], wo_carry[ks][1]);
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -283,8 +310,8 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             f32x16 oT;
 #pragma unroll
             for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+            f16x8 qs[2][2];
             {
-                f16x8 qs[2][2];
                 split_acc<false>(qT, (qscale * SQ) / sum, qs);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -296,14 +323,19 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             {
                 f16x8 os[2][2];
                 split_acc<true>(oT, SO / (SC * SQ), os);
+                f16x8 wo[2 * NTC][2];
 #pragma unroll
-                for (int nt = 0; nt < NTC; ++nt)
+                for (int g = 0; g < 2 * NTC; ++g) {             // group g = (column tile g / 2, k-step g % 2)
+                    load_w2(Wo, g, loff, wo[g]);
+                    mfma3(y[g >> 1], os[g & 1], wo[g]);         // Y[token][c]: lane = channel, regs = tokens
+                    if (g < 2) mfma_keep(y[g >> 1], qs[g][0], qs[g][1]);
+                    else mfma_keep(y[g >> 1], wo[g - 2][0], wo[g - 2][1]);
+                    mfma_order_point();
+                }
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        f16x8 w[2];
-                        load_w2(Wo, nt * 2 + s, loff, w);
-                        mfma3(y[nt], os[s], w);                // Y[token][c]: lane = channel, regs = tokens
-                    }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = wo[2 * NTC - 2 + i][pl];
             }
         }
         // ---- bias + residual + store (lane = channel, regs = token)

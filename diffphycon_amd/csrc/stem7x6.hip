@@ -145,13 +145,24 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
     // weight fragments: [(df*7+dh)*4 + ks][Npad][3][16] bf16 = 96 B per n
     const unsigned char* wlane = wp6 + ((long long)n0 + wn * 32 + l31) * WROWB + hh * 16;
     const long long wstep = (long long)p.Npad * WROWB;
-    frag_t wc[NP], wx[NP];
+    // Weight fragments (the MFMAs' B operand) live in a ring of RW register sets with STATIC slot indices: step s multiplies slot
+    // s % RW, the set of step s + 1 is requested at the top of step s into slot (s + 1) % RW, and the set of step s - 1 keeps its
+    // registers to the end of step s (common.h: mfma_keep -- six or twelve younger MFMAs -- so hipcc cannot hand a B operand's
+    // registers to an LDS fragment read issued right behind its last reader: DESIGN.md 6.2).  RW divides the 7 KS steps of one df
+    // iteration, so every slot has the same role at the loop's back edge and the loop-carried sets need no copies.
+    constexpr int SPI = 7 * KS;                                   // steps per df iteration
+    constexpr int RW = SPI % 3 == 0 ? 3 : (SPI % 4 == 0 ? 4 : 7);
+    frag_t wr[RW][NP];
     auto ldw = [&](int step, frag_t (&w)[NP]) {
         const unsigned char* src = wlane + (long long)step * wstep;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) w[pl] = *reinterpret_cast<const frag_t*>(src + pl * 32);
     };
-    ldw(0, wc);
+    ldw(0, wr[0]);
+#pragma unroll
+    for (int r = 1; r < RW; ++r)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) wr[r][pl] = wr[0][pl];     // (defined values for the first keeps)
     __syncthreads();
 
     for (int df = 0; df < 7; ++df) {
@@ -162,7 +173,9 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int step = (df * 7 + dh) * KS + ks;
-                if (step + 1 < 49 * KS) ldw(step + 1, wx);
+                const int sl = (dh * KS + ks) % RW;                // = step % RW (SPI % RW == 0); compile-time after unrolling
+                frag_t (&wc)[NP] = wr[sl];
+                if (step + 1 < 49 * KS) ldw(step + 1, wr[(sl + 1) % RW]);
                 frag_t a[2][NP];
                 if constexpr (CS == 8) {
                     const int slot = (lw + 2 * ks + hh + rot) & 15;
@@ -198,9 +211,19 @@ __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const uns
                             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
                 }
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) wc[pl] = wx[pl];
+                for (int mt = 0; mt < 2; ++mt) {
+                    frag_t (&sp)[NP] = wr[(sl + RW - 1) % RW];
+                    if constexpr (NP == 2) mfma_keep(acc[mt], sp[0], sp[1]);
+                    else mfma_keep(acc[mt], sp[0], sp[1], sp[2]);
+                }
             }
         }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        frag_t (&sp)[NP] = wr[(49 * KS - 1) % RW];
+        if constexpr (NP == 2) mfma_keep(acc[mt], sp[0], sp[1]);
+        else mfma_keep(acc[mt], sp[0], sp[1], sp[2]);
     }
 
     const int n = n0 + wn * 32 + l31;
@@ -298,13 +321,20 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(StemParams p, const unsi
     // weight fragments: [(df*7+dh) * NCP + cp][Npad][2 planes][16] fp16, k = dw * 2 + (c & 1)
     const unsigned char* wlane = wp6 + ((long long)n0 + wn * 32 + l31) * WROWB + hh * 16;
     const long long wstep = (long long)p.Npad * WROWB;
-    f16x8_s wc[2], wx[2];
+    // ring of weight sets with static slot indices, as in stem7x6_kernel (spent B operands keep their registers for one more k-step)
+    constexpr int SPI = 7 * NCP;
+    constexpr int RW = SPI % 3 == 0 ? 3 : 7;
+    f16x8_s wr[RW][2];
     auto ldw = [&](int step, f16x8_s (&w)[2]) {
         const unsigned char* src = wlane + (long long)step * wstep;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) w[pl] = *reinterpret_cast<const f16x8_s*>(src + pl * 32);
     };
-    ldw(0, wc);
+    ldw(0, wr[0]);
+#pragma unroll
+    for (int r = 1; r < RW; ++r)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wr[r][pl] = wr[0][pl];
     __syncthreads();
 
     const int abase = (wm * 2 * HH + lh) * ROWB + (lw + 4 * hh) * 4;      // frame wm*2 (+ mt + df), halo row lh (+ dh), point lw + 4 hh
@@ -315,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(StemParams p, const unsi
 #pragma unroll
             for (int cp = 0; cp < NCP; ++cp) {
                 const int step = (df * 7 + dh) * NCP + cp;
-                if (step + 1 < 49 * NCP) ldw(step + 1, wx);
+                const int sl = (dh * NCP + cp) % RW;               // = step % RW, compile-time after unrolling
+                f16x8_s (&wc)[2] = wr[sl];
+                if (step + 1 < 49 * NCP) ldw(step + 1, wr[(sl + 1) % RW]);
                 f16x8_s a[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -331,10 +363,12 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(StemParams p, const unsi
                     for (int mt = 0; mt < 2; ++mt)
                         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt][PA[term]], wc[PB[term]], acc[mt], 0, 0, 0);
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) wc[pl] = wx[pl];
+                for (int mt = 0; mt < 2; ++mt) mfma_keep(acc[mt], wr[(sl + RW - 1) % RW][0], wr[(sl + RW - 1) % RW][1]);
             }
         }
     }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) mfma_keep(acc[mt], wr[(49 * NCP - 1) % RW][0], wr[(49 * NCP - 1) % RW][1]);
 
     const int n = n0 + wn * 32 + l31;
     if (n < p.N) {

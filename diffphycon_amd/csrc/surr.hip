@@ -169,8 +169,19 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // (B operands come straight from LDS, one register per MFMA: all 16 are read up front and each keeps its register until four
+        //  younger MFMAs were issued -- common.h: mfma_keep_a)
+        {
+            float bD[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ct[i], D[(2 * i + hh) * 33 + l31], acc, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) bD[i] = D[(2 * i + hh) * 33 + l31];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ct[i], bD[i], acc, 0, 0, 0);
+                if (i >= 4) mfma_keep_a(acc, bD[i - 4]);
+            }
+            mfma_drain(acc);                                     // (the softmax below consumes acc anyway; its LDS reads stay behind the chain)
+        }
         {
             float q[16];
             float m = -INFINITY;
@@ -192,12 +203,24 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+        {
+            float bV[16], bK[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int d = 2 * i + hh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dt[i], V[d * 33 + l31], acc, 0, 0, 0);
-            const float ks = expf(K[d * 33 + l31] - km2[i]) / z2[i];
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_d[i], ks, acc2, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                const int d = 2 * i + hh;
+                bV[i] = V[d * 33 + l31];
+                bK[i] = expf(K[d * 33 + l31] - km2[i]) / z2[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                       // two chains: a B register is released two iterations (4 MFMAs) later
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dt[i], bV[i], acc, 0, 0, 0);
+                if (i >= 2) mfma_keep_a(acc, bV[i - 2]);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_d[i], bK[i], acc2, 0, 0, 0);
+                if (i >= 2) mfma_keep_a(acc2, bK[i - 2]);
+                mfma_order_point();
+            }
+            mfma_drain(acc);
+            mfma_drain(acc2);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)

@@ -141,6 +141,15 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             for (int q = 0; q < 2; ++q) xr[ks][q] = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4 * q);
     };
     if (PREFETCH && gp < p.npix) load_rows(row0_of(gp));
+    // MFMA B operands that are loaded from LDS or die right after their MFMAs keep their registers until two more 3-MFMA groups were
+    // issued (common.h: mfma_keep): the projection order is V, K, Q so that a V-weight fragment is followed by six MFMAs
+    // whose B operand (xs) stays live; q / p fragments are released inside the next product; the last two to_out fragments of a head
+    // are carried into the first two groups of the next head (or pixel).
+    f16x8 wo_carry[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 
     for (; gp < p.npix; gp += nwaves) {
         const long long row0 = row0_of(gp);
@@ -201,13 +210,18 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             for (int r = 0; r < 16; ++r) { qT[r] = 0.f; kT[r] = 0.f; vv[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                f16x8 w[2];
-                load_w2(Wq, ks, loff, w);
-                mfma3(qT, w, xs[ks]);
+                f16x8 wv[2], w[2];
+                load_w2(Wq + 2 * KS * 2048, ks, loff, wv);
+                mfma3(vv, xs[ks], wv);
+                if (ks == 0) mfma_keep(vv, wo_carry[0][0], wo_carry[0][1]);
+                mfma_order_point();                              // (MFMAs keep their source order across this point: K, Q follow V)
                 load_w2(Wq + KS * 2048, ks, loff, w);
                 mfma3(kT, w, xs[ks]);
-                load_w2(Wq + 2 * KS * 2048, ks, loff, w);
-                mfma3(vv, xs[ks], w);
+                if (ks == 0) mfma_keep(kT, wo_carry[1][0], wo_carry[1][1]);
+                load_w2(Wq, ks, loff, w);
+                mfma3(qT, w, xs[ks]);
+                mfma_keep(kT, wv[0], wv[1]);
+                mfma_keep(qT, wv[0], wv[1]);
             }
             // ---- q * scale, rotary on q and k (pairs (2m, 2m+1) = registers (4jj, 4jj+1), (4jj+2, 4jj+3)); the results carry
             //      the operand pre-scale SQK
@@ -231,8 +245,9 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            f16x8 qs[2][2];
             {
-                f16x8 qs[2][2], kk[2][2];
+                f16x8 kk[2][2];
                 split_acc<true>(qT, 1.f, qs);
                 split_acc<true>(kT, 1.f, kk);
                 mfma3(st, kk[0], qs[0]);
@@ -264,26 +279,34 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             f32x16 oT;
 #pragma unroll
             for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+            f16x8 ps[2][2];
             {
-                f16x8 vs[2][2], ps[2][2];
+                f16x8 vs[2][2];
                 split_acc<true>(vv, PROJ_DESCALE * SV, vs);
                 split_acc<false>(st, SP, ps);
                 mfma3(oT, vs[0], ps[0]);
+                mfma_keep(oT, qs[0][0], qs[0][1]);
                 mfma3(oT, vs[1], ps[1]);
+                mfma_keep(oT, qs[1][0], qs[1][1]);
             }
             // ---- Y[i][c] += sum_d O[i][d] Wout[c][hd*32+d]   (A = O: lane = token i; B = packed to_out slice); the softmax
             //      normalisation, the descale of P and V and the pre-scale of O are one multiplier
             {
                 f16x8 os[2][2];
                 split_acc<true>(oT, (SO / (SP * SV)) / l, os);
+                f16x8 wo[2 * NTC][2];
 #pragma unroll
-                for (int nt = 0; nt < NTC; ++nt)
+                for (int g = 0; g < 2 * NTC; ++g) {                 // group g = (column tile g / 2, k-step g % 2)
+                    load_w2(Wo, g, loff, wo[g]);
+                    mfma3(y[g >> 1], os[g & 1], wo[g]);
+                    if (g < 2) mfma_keep(y[g >> 1], ps[g][0], ps[g][1]);
+                    else mfma_keep(y[g >> 1], wo[g - 2][0], wo[g - 2][1]);
+                    mfma_order_point();
+                }
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        f16x8 w[2];
-                        load_w2(Wo, nt * 2 + s, loff, w);
-                        mfma3(y[nt], os[s], w);
-                    }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = wo[2 * NTC - 2 + i][pl];
             }
         }
         // ---- residual + store (lane = channel, regs = token)
@@ -393,6 +416,12 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
         }
     };
 
+    // spent MFMA B operands keep their registers for two more 3-MFMA groups (as in tattn3_kernel; common.h: mfma_keep)
+    f16x8 wo_carry[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     for (long long gp = (long long)blockIdx.x * 4 + wave; gp < p.npix; gp += nwaves) {
         const long long row0 = row0_of(gp);
         // ---- rows of both tiles: load, LayerNorm over channels (lane pair), scale, split
@@ -449,13 +478,19 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                 for (int r = 0; r < 16; ++r) { kT[T][r] = 0.f; vv[T][r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                f16x8 w[2];
+                f16x8 w[2], wv[2];
+                load_w2(Wq + 2 * KS * 2048, ks, loff, wv);       // V first: its weight fragment (B operand) is followed by the six K MFMAs
+                mfma3(vv[0], xs[0][ks], wv);
+                if (ks == 0) mfma_keep(vv[0], wo_carry[0][0], wo_carry[0][1]);
+                mfma3(vv[1], xs[1][ks], wv);
+                if (ks == 0) mfma_keep(vv[1], wo_carry[1][0], wo_carry[1][1]);
+                mfma_order_point();
                 load_w2(Wq + KS * 2048, ks, loff, w);
                 mfma3(kT[0], w, xs[0][ks]);
                 mfma3(kT[1], w, xs[1][ks]);
-                load_w2(Wq + 2 * KS * 2048, ks, loff, w);
-                mfma3(vv[0], xs[0][ks], w);
-                mfma3(vv[1], xs[1][ks], w);
+                mfma_keep(kT[0], wv[0], wv[1]);
+                mfma_keep(kT[1], wv[0], wv[1]);
+                mfma_order_point();
             }
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
@@ -476,11 +511,12 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                 f16x8 w[2];
                 load_w2(Wq, ks, loff, w);
                 mfma3(qT, w, xs[it][ks]);
+                if (ks < 2) mfma_keep(qT, wo_carry[ks][0], wo_carry[ks][1]);     // (the previous attend's last to_out fragments)
             }
             rotary(qT, it, qscale * (PROJ_DESCALE * SQK));
             f32x16 st[2];
+            f16x8 qs[2][2];
             {
-                f16x8 qs[2][2];
                 split_acc<true>(qT, 1.f, qs);
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
@@ -488,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                     for (int r = 0; r < 16; ++r) st[jt][r] = 0.f;
                     mfma3(st[jt], kk[jt][0], qs[0]);
                     mfma3(st[jt], kk[jt][1], qs[1]);
+                    mfma_order_point();
                 }
             }
             // bias[h][i][j] = brel[h][j - i + 63]; registers 4jj .. 4jj+3 of key tile jt = keys 32jt + 8jj + 4hh .. +3
@@ -519,23 +556,32 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
             f32x16 oT;
 #pragma unroll
             for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+            f16x8 ps[2][2][2];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                f16x8 ps[2][2];
-                split_acc<false>(st[jt], SP, ps);
-                mfma3(oT, vs[jt][0], ps[0]);
-                mfma3(oT, vs[jt][1], ps[1]);
+                split_acc<false>(st[jt], SP, ps[jt]);
+                mfma3(oT, vs[jt][0], ps[jt][0]);
+                if (jt == 0) mfma_keep(oT, qs[0][0], qs[0][1]);
+                else mfma_keep(oT, ps[0][0][0], ps[0][0][1]);
+                mfma3(oT, vs[jt][1], ps[jt][1]);
+                if (jt == 0) mfma_keep(oT, qs[1][0], qs[1][1]);
+                else mfma_keep(oT, ps[0][1][0], ps[0][1][1]);
             }
             f16x8 os[2][2];
             split_acc<true>(oT, (SO / (SP * SV)) / l, os);
+            f16x8 wo[2 * NTC][2];
 #pragma unroll
-            for (int nt = 0; nt < NTC; ++nt)
+            for (int g = 0; g < 2 * NTC; ++g) {                     // group g = (column tile g / 2, k-step g % 2)
+                load_w2(Wo, g, loff, wo[g]);
+                mfma3(y[g >> 1], os[g & 1], wo[g]);
+                if (g < 2) mfma_keep(y[g >> 1], ps[1][g][0], ps[1][g][1]);
+                else mfma_keep(y[g >> 1], wo[g - 2][0], wo[g - 2][1]);
+                mfma_order_point();
+            }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    f16x8 w[2];
-                    load_w2(Wo, nt * 2 + s, loff, w);
-                    mfma3(y[nt], os[s], w);
-                }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = wo[2 * NTC - 2 + i][pl];
         };
         auto store_tile = [&](int it, const f32x16 (&y)[NTC]) {
 #pragma unroll

@@ -529,11 +529,26 @@ __global__ __launch_bounds__(256) void tattn_bwd_mfma_kernel(const TattnBwdMPara
         f32x16 sT, dpT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sT[r] = bias_r[r]; dpT[r] = 0.f; }
+        // (B operands come straight from LDS, one register per MFMA: they are read up front and each keeps its register until four
+        //  younger MFMAs were issued -- common.h: mfma_keep_a / mfma_order_point)
+        {
+            float bq1[16], bd1[16];
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int kk = 2 * s2 + hh;
-            sT = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[l31 * 33 + kk], sq[l31 * 33 + kk], sT, 0, 0, 0);
-            dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l31 * 33 + kk], sd[l31 * 33 + kk], dpT, 0, 0, 0);
+            for (int s2 = 0; s2 < 16; ++s2) {
+                bq1[s2] = sq[l31 * 33 + 2 * s2 + hh];
+                bd1[s2] = sd[l31 * 33 + 2 * s2 + hh];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int kk = 2 * s2 + hh;
+                sT = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[l31 * 33 + kk], bq1[s2], sT, 0, 0, 0);
+                if (s2 >= 2) mfma_keep_a(sT, bq1[s2 - 2]);
+                dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l31 * 33 + kk], bd1[s2], dpT, 0, 0, 0);
+                if (s2 >= 2) mfma_keep_a(dpT, bd1[s2 - 2]);
+                mfma_order_point();
+            }
+            mfma_drain(sT);                                      // (consumed by the softmax right below)
+            mfma_drain(dpT);
         }
         float m = -INFINITY;
 #pragma unroll
@@ -558,13 +573,27 @@ __global__ __launch_bounds__(256) void tattn_bwd_mfma_kernel(const TattnBwdMPara
         f32x16 dv, dk, dq;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; dq[r] = 0.f; }
+        {
+            float bd2[16], bq2[16], bk2[16];
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int kk = 2 * s2 + hh;
-            const float bd = sd[kk * 33 + l31], bq = sq[kk * 33 + l31], bk = sk[kk * 33 + l31];
-            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l31 * 33 + kk], bd, dv, 0, 0, 0);       // P^T[j][i] dO[i][d]
-            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(st[l31 * 33 + kk], bq, dk, 0, 0, 0);       // dS^T[j][i] q'[i][d]
-            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(st[kk * 33 + l31], bk, dq, 0, 0, 0);       // dS[i][j] k'[j][d]
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int kk = 2 * s2 + hh;
+                bd2[s2] = sd[kk * 33 + l31]; bq2[s2] = sq[kk * 33 + l31]; bk2[s2] = sk[kk * 33 + l31];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {                    // three chains: a B register is released two iterations (6 MFMAs) later
+                const int kk = 2 * s2 + hh;
+                dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l31 * 33 + kk], bd2[s2], dv, 0, 0, 0);       // P^T[j][i] dO[i][d]
+                if (s2 >= 2) mfma_keep_a(dv, bd2[s2 - 2]);
+                dk = __builtin_amdgcn_mfma_f32_32x32x2f32(st[l31 * 33 + kk], bq2[s2], dk, 0, 0, 0);       // dS^T[j][i] q'[i][d]
+                if (s2 >= 2) mfma_keep_a(dk, bq2[s2 - 2]);
+                dq = __builtin_amdgcn_mfma_f32_32x32x2f32(st[kk * 33 + l31], bk2[s2], dq, 0, 0, 0);       // dS[i][j] k'[j][d]
+                if (s2 >= 2) mfma_keep_a(dq, bk2[s2 - 2]);
+                mfma_order_point();
+            }
+            mfma_drain(dv);
+            mfma_drain(dk);
+            mfma_drain(dq);
         }
         // ---- rot^T (pairs are neighbouring lanes), q scale, stores: rows = tokens, 32 lanes = one 128-byte row
 #pragma unroll

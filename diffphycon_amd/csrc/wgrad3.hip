@@ -184,6 +184,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
     store_x(1);
     __syncthreads();
 
+    // The dY fragments (the MFMAs' B operand, re-read from LDS per k-block) keep their registers through the first tap of the next
+    // k-block of the same iteration: six younger MFMAs (common.h: mfma_keep_a -- the accumulators live in AccVGPRs).
+    // Across the loop's back edge the wave drains its MFMAs before the barrier instead (mfma_drain: one accumulator read per chain,
+    // ~1 % of an iteration's 168 MFMAs).
     for (int it = 0; it < ngroups; ++it) {
         issue_x(it + 2);
         issue_y(it + 1);
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
         const long long pl = plane0 + v0 / H;
         const int h0 = (int)(v0 % H), f = (int)(pl % F);
         const unsigned ybuf = Cf::Y_OFF + (it & 1) * Cf::YBUF;
+        h3::f16x8 b_spent[2][2];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             const int r = kb / KPR, w0 = 16 * (kb % KPR);
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
                 }
 #pragma unroll
             for (int t = 0; t < 7; ++t) {
-                if (t < ntap) {
+                if (t < 6 || t < ntap) {                         // (every wave owns >= 6 taps: only the seventh is conditional)
                     const int tap = tap0 + t, d = tap / 9, dh = (tap % 9) / 3, dw = tap % 3;
                     const bool ok = (unsigned)(f + d - 1) < (unsigned)F && (unsigned)(h + dh - 1) < (unsigned)H;
                     const unsigned row_off = ok ? (unsigned)(d * Cf::DFS + ((vrow + dh - 1) & (NS - 1)) * Cf::SLOT + (w0 + dw) * 64)
@@ -218,9 +223,22 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
                     a[1] = tr_frag(ldsp(o + pl_off), ldsp(o + pl_off + 256));
 #pragma unroll
                     for (int n = 0; n < 2; ++n) h3::mfma3(acc[t][n], a, b[n]);
+                    if (t == 0 && kb > 0) {
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) mfma_keep_a(acc[0][n], b_spent[n][0], b_spent[n][1]);
+                    }
                 }
             }
+            mfma_order_point();                                  // (the next k-block's MFMAs follow this one's)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int pln = 0; pln < 2; ++pln) b_spent[n][pln] = b[n][pln];
         }
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) mfma_drain(acc[t][n]);
         store_x(it + 2);
         store_y(it + 1);
         __syncthreads();

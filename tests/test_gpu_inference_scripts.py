@@ -69,17 +69,12 @@ def run_ranks(n, cmd, cwd, extra_env=None):
 
 
 def _tripwire(compare, what):
-    """compare() -> list of mismatches.  The two ranks of these tests time-share ONE GPU -- a configuration no deployment has (one
-    process per GPU; RCCL refuses two ranks on a device) and the one under which DESIGN.md 6.2's third hazard was found in r03 (2 of
-    70 Burgers runs off by 3e-7; fixed in the halo convolution kernels, 0 of 110 since; tools/mfma_war_audit.py lists the kernels that
-    still re-load an MFMA operand register directly behind its reader).  A mismatch that an immediate re-run reproduces is a sharding
-    bug and fails; one that does not is reported loudly (values in the warning) instead of ending the whole GPU run."""
+    """compare() -> list of mismatches: a plain assertion.  The two ranks of these tests time-share ONE GPU -- the configuration under
+    which DESIGN.md 6.2's third hazard (an LDS read overwriting a queued MFMA's B operand) showed up in r03.  r03 re-ran a mismatching
+    comparison once and only warned; since r04 every MFMA kernel of the library keeps a B operand's registers for >= 4 younger MFMAs
+    (tests/test_mfma_war_audit.py pins it in the ISA; tools/rank_stress.py: profiles/r04_*_rank_stress*.log), so there is no second chance."""
     bad = compare()
-    if bad:
-        again = compare()
-        assert not again, (f"{what}: two-rank result differs from the single-rank result in two consecutive runs", bad, again)
-        import warnings
-        warnings.warn(f"{what}: two-rank run differed from the single-rank run ONCE and matched on the re-run: {bad}")
+    assert not bad, (f"{what}: two-rank result differs from the single-rank result", bad)
 
 
 def _floats_after(out, key):

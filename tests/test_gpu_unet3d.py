@@ -21,8 +21,8 @@ def dev():
 
 # per-block outputs rel 1e-5 (of the tensor's range), the full forward rel 1e-4.  Asserted: the per-block bar for every
 # tap, and for the output what was MEASURED x 3 (profiles/r04_tolerances.json: worst tap / output over all cases of this file).
-TAP_TOL = 1e-4
-OUT_TOL = 1e-4
+TAP_TOL = 1e-5            # measured worst tap 3.2e-6
+OUT_TOL = 1e-5            # measured worst output 3.1e-6
 
 
 def _model_from_golden(g, prefix, dev, channels, dim, mults, micro_batch=0, arithmetic=None):
@@ -134,26 +134,48 @@ def _oracle_parity(dev, cfg_kw, seed, shape, t, tol=None, arithmetic=None):
     return m
 
 
-_FULL_EXTENT = {
-    # BASELINE.json configs at their FULL per-trajectory extent, B = 1, default arithmetic (f16x3, Winograd 3x3x3 convs):
-    # the shapes where the 4x4 / 8x8-multiple levels all take conv3w, the persistent loops walk many tiles per workgroup
-    # and the XCD-aware tile decode sees the production tile counts.  CPU oracle cost: ~3 s (S64), ~40 s (S128), ~12 s (J128).
-    "s64_joint": (dict(dim=64, dim_mults=(1, 2, 4), channels=6), 41, (1, 32, 6, 64, 64), [611]),
-    "s64_prior": (dict(dim=64, dim_mults=(1, 2, 4), channels=2), 42, (1, 32, 2, 64, 64), [7]),
-    "s128": (dict(dim=64, dim_mults=(1, 2, 4), channels=6), 43, (1, 64, 6, 128, 128), [250]),
-    "j128_state": (dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=4), 44, (1, 20, 7, 128, 128), [999]),
-    "j128_theta": (dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=1), 45, (1, 20, 7, 128, 128), [3]),
-}
-
-
-@pytest.mark.parametrize("case", list(_FULL_EXTENT))
+@pytest.mark.parametrize("case", ["s64_joint", "s64_prior", "s128", "j128_state", "j128_theta"])
 def test_full_extent_vs_oracle(case, dev):
-    """HIP forward (default mode) vs oracle.unet3d_forward at the FULL extent of S64 (32 x 64 x 64, joint and prior nets),
-    S128 (64 x 128 x 128) and J128 (20 x 128 x 128, 7 -> 4 and 7 -> 1), every tap and the output at 2e-5 of the tensor range
-    (...conv3d.py:486-552).  A deterministic, batch-independent full-size bug -- which the invariance tests below cannot see --
-    fails here."""
-    cfg_kw, seed, shape, t = _FULL_EXTENT[case]
-    _oracle_parity(dev, cfg_kw, seed, shape, t)
+    """HIP forward (default mode: f16x3, Winograd 3x3x3 convs) vs oracle.unet3d_forward at the FULL per-trajectory extent of S64 (32 x 64 x
+    64, joint and prior nets), S128 (64 x 128 x 128) and J128 (20 x 128 x 128, 7 -> 4 and 7 -> 1), B = 1: the shapes where every level
+    takes conv3w, the persistent loops walk many tiles per workgroup and the XCD-aware tile decode sees the production tile counts
+    (...conv3d.py:486-552).  A deterministic, batch-independent full-size bug -- which the invariance tests cannot see -- fails here.
+    The oracle side (minutes of host time per case) is a committed fixture: tools/gen_golden_r04.py recorded, for every tap and the
+    output, the tensor's shape, max |value| and 4096 values at seeded positions (tests/golden/full_extent_<case>.npz; the s64_prior file
+    is re-derived from the oracle by tests/test_oracle_unet3d.py).  Compared at TAP_TOL / OUT_TOL of the tensor's range."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_golden_r04 as G
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    g = load_golden(f"full_extent_{case}")
+    cfg_kw, seed, x, tt = G.full_extent_inputs(case)
+    m = Unet3D_with_Conv3D(**cfg_kw)
+    m.load_state_dict(O.synthetic_state_dict(O.Unet3DConfig(**cfg_kw), seed=seed))
+    m = m.to(dev)
+    m.debug_taps(True)
+    y = m(x.to(dev), tt.to(dev))
+    bad, checked = [], 0
+    for k, name in enumerate(g["names"]):
+        shape = tuple(int(v) for v in g[f"shape:{name}"])
+        if name == "y":
+            got = y
+            assert tuple(y.shape) == shape
+        else:
+            try:
+                got = m.get_tap(name, shape, dev)
+            except RuntimeError:
+                continue
+        idx = torch.from_numpy(G.sample_index(seed, k, got.numel())).to(dev)
+        vals = got.reshape(-1)[idx].cpu()
+        ref = torch.from_numpy(g[f"values:{name}"])
+        err = note_error(name, ((vals - ref).abs().max() / float(g[f"absmax:{name}"])).item())
+        checked += 1
+        if err > (OUT_TOL if name == "y" else TAP_TOL):
+            bad.append((name, err))
+    assert not bad, bad
+    assert checked >= 30, checked
 
 
 def test_s128_sequence_length_64_frames_vs_oracle(dev):
@@ -549,17 +571,15 @@ def test_full_width_100_step_chain_f16x3_drift_vs_exact_and_oracle(dev):
     from oracle import sampler_smoke as S
     from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, SmokeGuidance
     from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
-    T, F_, HW = 100, 8, 16
-    cj, cw = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6), O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=2)
-    sdj, sdw = O.synthetic_state_dict(cj, seed=51), O.synthetic_state_dict(cw, seed=52)
-    gen = torch.Generator().manual_seed(53)
-    noises = torch.randn(T + 1, 1, F_, 6, HW, HW, generator=gen)
-    init = torch.rand(1, HW, HW, generator=gen) * 2 - 1
-    kw = dict(standard_fixed_ratio=0.01, w_prob_exp=0.97, w_energy=0.0, design_guidance="standard", coeff_ratio=0.0)
-    with torch.no_grad():
-        ref = S.p_sample_loop(S.make_schedule(T, "sigmoid"), lambda x, t: O.unet3d_forward(sdj, cj, x, t),
-                              lambda x, t: O.unet3d_forward(sdw, cw, x, t), (1, F_, 6, HW, HW), init, S.rescaler_tensor(),
-                              list(noises), **kw)
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_golden_r04 as G
+    T, F_, HW = G.DRIFT["T"], G.DRIFT["F"], G.DRIFT["HW"]
+    cj, cw, sdj, sdw, noises, init = G.drift_chain_inputs()
+    # the oracle's chain (200 full-width CPU forwards: minutes) is the committed fixture tests/golden/drift_chain.npz
+    # (tools/gen_golden_r04.py; its first steps are re-derived on the CPU by tests/test_oracle_unet3d.py)
+    ref = torch.from_numpy(load_golden("drift_chain")["final"])
     outs = {}
     for mode in ("f16x3", "x6"):
         mj = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, arithmetic=mode)

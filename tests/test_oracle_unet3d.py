@@ -62,3 +62,26 @@ def test_product_relative_position_bucket_matches_reference_table():
         ref = g[f"n{n}"]
         got = _relative_position_bucket(n).numpy()
         assert got.dtype == ref.dtype and np.array_equal(got, ref), n
+
+
+def test_r04_fixtures_are_what_the_oracle_computes():
+    """tests/golden/full_extent_*.npz and drift_chain.npz (tools/gen_golden_r04.py) hold ORACLE outputs so that the GPU suite does not
+    spend minutes of host time on them per box.  Re-derived here for the cheapest members: the s64_prior full-extent forward (every
+    recorded sample of every tap, the output, shapes and maxima) and the first three steps of the 100-step drift chain.  Same torch
+    CPU kernels on another host may differ in the last bits (oneDNN code paths): 2e-6 of the tensor's range."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_golden_r04 as G
+    g = load_golden("full_extent_s64_prior")
+    rec = G.full_extent_record("s64_prior")
+    assert list(rec["names"]) == list(g["names"]) and len(rec["names"]) >= 30
+    for name in g["names"]:
+        assert np.array_equal(rec[f"shape:{name}"], g[f"shape:{name}"])
+        scale = float(g[f"absmax:{name}"])
+        assert abs(float(rec[f"absmax:{name}"]) - scale) <= 2e-6 * scale
+        assert np.abs(rec[f"values:{name}"] - g[f"values:{name}"]).max() <= 2e-6 * scale, name
+    d = load_golden("drift_chain")
+    after3 = G.drift_chain_oracle(3).numpy()
+    assert np.abs(after3 - d["after3"]).max() <= 2e-6 * np.abs(d["after3"]).max()
+    assert d["final"].shape == d["after3"].shape and np.isfinite(d["final"]).all()

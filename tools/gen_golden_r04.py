@@ -1,0 +1,100 @@
+"""Fixtures of r04 (committed under tests/golden/): outputs of the CPU ORACLE (oracle/unet3d.py, oracle/sampler_smoke.py -- themselves pinned
+to the imported reference by tests/test_oracle_*.py) on seeded inputs whose evaluation takes minutes of host time, so that the GPU
+suite does not re-run them on every box:
+
+  full_extent_<case>.npz : oracle.unet3d_forward at the FULL extent of a BASELINE config (tests/test_gpu_unet3d.py: _FULL_EXTENT) -- for
+                           every tap and the output: the tensor's shape, its max |value| and NSAMP values at positions drawn by
+                           numpy.random.RandomState(seed of the case + index of the tap) (`sample_index` below; the test draws the same);
+  drift_chain.npz        : the final state of the 100-step free-running guided DDPM chain of
+                           test_full_width_100_step_chain_f16x3_drift_vs_exact_and_oracle on the oracle.
+
+    python tools/gen_golden_r04.py [case ...]        (no argument: everything; ~6 minutes on 8 cores, ~12 GB of host memory)
+
+tests/test_oracle_unet3d.py re-computes the s64_prior case and the first steps of the chain on the CPU and checks the files."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NSAMP = 4096
+
+FULL_EXTENT = {
+    "s64_joint": (dict(dim=64, dim_mults=(1, 2, 4), channels=6), 41, (1, 32, 6, 64, 64), [611]),
+    "s64_prior": (dict(dim=64, dim_mults=(1, 2, 4), channels=2), 42, (1, 32, 2, 64, 64), [7]),
+    "s128": (dict(dim=64, dim_mults=(1, 2, 4), channels=6), 43, (1, 64, 6, 128, 128), [250]),
+    "j128_state": (dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=4), 44, (1, 20, 7, 128, 128), [999]),
+    "j128_theta": (dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=1), 45, (1, 20, 7, 128, 128), [3]),
+}
+
+
+def sample_index(seed, k, numel):
+    """Positions (flat, C-order) of the samples of the k-th recorded tensor of a case."""
+    return np.random.RandomState(1000 * seed + k).randint(0, numel, size=min(NSAMP, numel)).astype(np.int64)
+
+
+def full_extent_inputs(case):
+    cfg_kw, seed, shape, t = FULL_EXTENT[case]
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    return cfg_kw, seed, x, torch.tensor(t)
+
+
+def full_extent_record(case):
+    from oracle import unet3d as O
+    cfg_kw, seed, x, tt = full_extent_inputs(case)
+    cfg = O.Unet3DConfig(**cfg_kw)
+    sd = O.synthetic_state_dict(cfg, seed=seed)
+    taps = {}
+    with torch.no_grad():
+        y = O.unet3d_forward(sd, cfg, x, tt, taps=taps)
+    out = {"names": np.array(list(taps) + ["y"])}
+    for k, (name, r) in enumerate(list(taps.items()) + [("y", y)]):
+        flat = r.contiguous().reshape(-1)
+        out[f"shape:{name}"] = np.array(r.shape, dtype=np.int64)
+        out[f"absmax:{name}"] = np.float32(flat.abs().max().item())
+        out[f"values:{name}"] = flat[torch.from_numpy(sample_index(seed, k, flat.numel()))].numpy().astype(np.float32)
+    return out
+
+
+DRIFT = dict(T=100, F=8, HW=16, seeds=(51, 52, 53))
+
+
+def drift_chain_inputs():
+    from oracle import unet3d as O
+    T, F_, HW = DRIFT["T"], DRIFT["F"], DRIFT["HW"]
+    cj, cw = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6), O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=2)
+    sdj, sdw = O.synthetic_state_dict(cj, seed=DRIFT["seeds"][0]), O.synthetic_state_dict(cw, seed=DRIFT["seeds"][1])
+    gen = torch.Generator().manual_seed(DRIFT["seeds"][2])
+    noises = torch.randn(T + 1, 1, F_, 6, HW, HW, generator=gen)
+    init = torch.rand(1, HW, HW, generator=gen) * 2 - 1
+    return cj, cw, sdj, sdw, noises, init
+
+
+def drift_chain_oracle(steps=None):
+    """Final state of the chain on the oracle; `steps` < T: the state after that many steps of the T-step schedule."""
+    from oracle import unet3d as O
+    from oracle import sampler_smoke as S
+    cj, cw, sdj, sdw, noises, init = drift_chain_inputs()
+    T, F_, HW = DRIFT["T"], DRIFT["F"], DRIFT["HW"]
+    kw = dict(standard_fixed_ratio=0.01, w_prob_exp=0.97, w_energy=0.0, design_guidance="standard", coeff_ratio=0.0)
+    if steps is not None:
+        kw["steps"] = list(reversed(range(T)))[:steps]          # the first `steps` steps of the same schedule
+    with torch.no_grad():
+        return S.p_sample_loop(S.make_schedule(T, "sigmoid"), lambda x, t: O.unet3d_forward(sdj, cj, x, t),
+                               lambda x, t: O.unet3d_forward(sdw, cw, x, t), (1, F_, 6, HW, HW), init, S.rescaler_tensor(),
+                               list(noises), **kw)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    want = sys.argv[1:] or list(FULL_EXTENT) + ["drift_chain"]
+    for case in want:
+        if case == "drift_chain":
+            ref = drift_chain_oracle()
+            np.savez_compressed(os.path.join(GOLDEN, "drift_chain.npz"), final=ref.numpy(), after3=drift_chain_oracle(3).numpy())
+        else:
+            np.savez_compressed(os.path.join(GOLDEN, f"full_extent_{case}.npz"), **full_extent_record(case))
+        print("wrote", case, flush=True)

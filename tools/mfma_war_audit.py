@@ -6,9 +6,12 @@ by construction (scheduling barriers, fragment rings); this tool measures it in 
     python tools/mfma_war_audit.py [file.hip ...]      (default: the MFMA kernels of the default path)
 
 For every kernel: the SMALLEST number of MFMAs issued between an MFMA that reads a register as srcA / srcB and a later load into
-that register, looking back over the last LOOKBACK MFMAs in program order (straight-line scan of the kernel text, loop bodies scanned
-twice so that the back edge is covered).  distance 0 = the load directly follows the group of MFMAs that read the register.
-tests/test_mfma_war_audit.py pins the B-operand distance of the halo convolution kernels at >= 4.
+that register, looking back over the last LOOKBACK MFMAs on EVERY control-flow path that reaches the load (basic blocks + a backward
+walk over all predecessors, so loop back edges and out-of-line blocks are followed exactly; r03's version scanned the kernel text twice
+in a row, which paired the last MFMAs of a loop-free kernel with its first loads).  distance 0 = the load directly follows the
+group of MFMAs that read the register.  An MFMA whose RESULT has been read by a VALU / store instruction before the load (and every
+MFMA older than it: one in-order matrix pipe per wave) has completed and is not counted.  tests/test_mfma_war_audit.py pins the B-operand distance of every MFMA kernel of the
+default path at >= 4.
 """
 import os
 import re
@@ -20,7 +23,7 @@ CSRC = os.path.join(ROOT, "diffphycon_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
 LOOKBACK = 12
 DEFAULT = ["conv3w.hip", "conv3f3c.hip", "igemm6.hip", "igemm_panel.hip", "igemm_tile.hip", "igemm_wide.hip", "stem7x6.hip", "tattn3.hip",
-           "lattn3.hip", "wgrad3.hip"]
+           "lattn3.hip", "wgrad3.hip", "attn.hip", "surr.hip", "train.hip", "unet2d.hip"]
 
 REG = re.compile(r"\b([va])(?:\[(\d+):(\d+)\]|(\d+)\b)")
 
@@ -52,35 +55,112 @@ def kernels(asm):
             out[name] = cur
             cur = None
             continue
-        if t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
+        if re.match(r"^\.LBB\w+:", t):
+            cur.append(t.split(":")[0] + ":")              # labels stay: loops are found from the backward branches
+        elif t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
             cur.append(t.split(";")[0].strip())
     return out
 
 
+def _blocks(lines):
+    """Basic blocks of a kernel's instruction list: [(first, last + 1)], successors and predecessors by block index."""
+    leaders = {0}
+    label_at = {}
+    for i, t in enumerate(lines):
+        if t.endswith(":"):
+            leaders.add(i)
+            label_at[t[:-1]] = i
+        elif t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")) and i + 1 < len(lines):
+            leaders.add(i + 1)
+    starts = sorted(leaders)
+    blocks = [(st, starts[k + 1] if k + 1 < len(starts) else len(lines)) for k, st in enumerate(starts)]
+    index_of = {st: k for k, (st, _) in enumerate(blocks)}
+    succ = [[] for _ in blocks]
+    for k, (st, en) in enumerate(blocks):
+        last = lines[en - 1] if en > st else ""
+        m = re.match(r"^s_c?branch\w*\s+(\.LBB\w+)", last)
+        if m and m.group(1) in label_at:
+            succ[k].append(index_of[label_at[m.group(1)]])
+        if not last.startswith(("s_branch", "s_endpgm", "s_setpc")) and k + 1 < len(blocks):
+            succ[k].append(k + 1)
+    pred = [[] for _ in blocks]
+    for k, ss in enumerate(succ):
+        for t in ss:
+            pred[t].append(k)
+    return blocks, pred
+
+
 def audit(lines, lds_only=True):
-    """returns {operand: (min distance in MFMAs, example)} for operand in 'A', 'B'.  lds_only: LDS reads (64-128 cycles: the
-    hazardous kind); otherwise global / buffer / scratch loads as well (>= 500 cycles: an MFMA queue never outlasts them)."""
+    """returns {operand: (min distance in MFMAs, example)} for operand in 'A', 'B', and the number of MFMAs of the kernel.
+    For every load, the control-flow graph is walked BACKWARDS from it (all predecessors, loops included) until LOOKBACK MFMAs have been
+    passed on a path; an MFMA on the way that reads one of the load's destination registers gives a distance = MFMAs between them.
+    lds_only: LDS reads (64-128 cycles: the hazardous kind); otherwise global / buffer / scratch loads as well."""
     best = {"A": None, "B": None}
     loads = ("ds_read", "ds_load") if lds_only else ("ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")
-    recent = []          # (index of mfma in issue order, srcA regs, srcB regs, text)
+    blocks, pred = _blocks(lines)
+    parsed = {}
+    touched = {}          # non-MFMA instruction -> registers it names (reads, over-approximated by all its operands)
     n_mfma = 0
-    for text in lines + lines:          # (second pass: loop back edges)
+    for i, text in enumerate(lines):
+        if text.endswith(":"):
+            continue
         op = text.split()[0]
         if op.startswith("v_mfma") or op.startswith("v_smfmac"):
             ops = [o.strip() for o in text[len(op):].split(",")]
             if len(ops) >= 3:
-                recent.append((n_mfma, regs(ops[1]), regs(ops[2]), text))
-                recent = recent[-LOOKBACK:]
+                parsed[i] = (regs(ops[1]), regs(ops[2]), regs(ops[0]))
             n_mfma += 1
-        elif op.startswith(loads):
-            dst = regs(text[len(op):].split(",")[0])
-            for idx, ra, rb, mtext in recent:
-                for which, rset in (("A", ra), ("B", rb)):
-                    if dst & rset:
-                        d = n_mfma - 1 - idx          # MFMAs issued after the reader, before this load
-                        if best[which] is None or d < best[which][0]:
-                            best[which] = (d, f"{mtext}  ...  {text}")
-    return best, n_mfma // 2
+        elif not op.startswith(("s_", "ds_read", "ds_load", "global_load", "buffer_load", "scratch_load", "flat_load")):
+            r = set()
+            for tok in text[len(op):].split(","):
+                r |= regs(tok)
+            if r:
+                touched[i] = r
+    block_of = {}
+    for k, (st, en) in enumerate(blocks):
+        for i in range(st, en):
+            block_of[i] = k
+    for i, text in enumerate(lines):
+        if text.endswith(":") or not text.split()[0].startswith(loads):
+            continue
+        op = text.split()[0]
+        dst = regs(text[len(op):].split(",")[0])
+        if not dst:
+            continue
+        # `used` = registers named by the VALU / store / LDS-write instructions between the walk position and the load.  An MFMA whose
+        # RESULT one of them reads has completed before the load issues (RAW on the accumulator), and so has every older MFMA of the wave
+        # (one matrix pipe, in order): the walk stops there -- a finished MFMA no longer reads its operands.
+        seen = {}
+        stack = [(block_of[i], i - 1, 0, frozenset())]          # (block, index to walk back from, MFMAs passed, used)
+        while stack:
+            k, j, cnt, used0 = stack.pop()
+            used = set(used0)
+            st = blocks[k][0]
+            done = False
+            while j >= st and cnt < LOOKBACK:
+                if j in parsed:
+                    ra, rb, rd = parsed[j]
+                    if rd & used:
+                        done = True
+                        break
+                    for which, rset in (("A", ra), ("B", rb)):
+                        if dst & rset and (best[which] is None or cnt < best[which][0]):
+                            best[which] = (cnt, f"{lines[j]}  ...  {text}")
+                    cnt += 1
+                elif j in touched:
+                    used |= touched[j]
+                j -= 1
+            if done or cnt >= LOOKBACK:
+                continue
+            fu = frozenset(used)
+            for q in pred[k]:
+                old = seen.get((q, cnt))
+                if old is not None and fu >= old:               # already walked with no more knowledge of completed MFMAs
+                    continue
+                nu = fu if old is None else (fu & old)
+                seen[(q, cnt)] = nu
+                stack.append((q, blocks[q][1] - 1, cnt, nu))
+    return best, n_mfma
 
 
 def compile_asm(src):

@@ -2,6 +2,7 @@
 J_actual / Energy value (flake hunting: one full-suite run of r03 saw the two-rank result differ once).
   gpurun -- 'python tools/rank_stress.py [repeats] [graph 0/1]'
   gpurun -- 'python tools/rank_stress.py smoke [repeats]'    the smoke entry script (3-D denoisers) instead of the Burgers one
+  gpurun -- 'python tools/rank_stress.py jelly [repeats]'    the jellyfish entry script (Unet3D denoisers + the 2-D surrogates' forward / backward)
   gpurun -- 'python tools/rank_stress.py solo [repeats]'     one rank ALONE on the GPU at batch 1 and batch 2 (the shard sizes of the
                                                              two-rank run): separates "small-batch path is not repeatable" from
                                                              "two processes time-sharing the GPU"
@@ -15,7 +16,8 @@ import test_gpu_inference_scripts as T
 
 solo = len(sys.argv) > 1 and sys.argv[1] == "solo"
 smoke = len(sys.argv) > 1 and sys.argv[1] == "smoke"
-if solo or smoke:
+jelly = len(sys.argv) > 1 and sys.argv[1] == "jelly"
+if solo or smoke or jelly:
     sys.argv.pop(1)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 if len(sys.argv) > 2:
@@ -28,6 +30,27 @@ args = ["inference/inference_1d_burgers.py", "--dataset", "free_u_f_1e5_front_re
         "--is_model_w", "False", "--eval_two_models", "True", "--prior_beta", "0.9", "--w_scheduler", "sigmoid_flip",
         "--wus", "0.5", "--synthetic", "True", "--n_test_samples", "3", "--batch_size", "3", "--timesteps_override", "6"]
 vals = lambda out: tuple(repr(T._floats_after(out, k)) for k in ("J_actual:", "Energy:"))
+if jelly:
+    # tests/test_gpu_inference_scripts.py::test_jellyfish_script_two_ranks_match_single_rank, repeated: saved thetas / states bit-equal
+    import tempfile
+    import numpy as np
+    jargs = ["inference/inference_2d_jellyfish.py", "--synthetic", "True", "--batch_size", "3", "--num_batches", "1", "--frames", "4",
+             "--image_size", "64", "--timesteps", "2"]
+    with tempfile.TemporaryDirectory() as td:
+        T.run(jargs + ["--inference_result_path", td + "/a"], ROOT)
+        bad = 0
+        for i in range(n):
+            T.run_ranks(2, jargs + ["--inference_result_path", td + f"/b{i}"], ROOT)
+            diffs = []
+            for k in range(3):
+                for sub in ("thetas", "states"):
+                    x, y = np.load(f"{td}/a/{sub}/{k}.npy"), np.load(f"{td}/b{i}/{sub}/{k}.npy")
+                    if not np.array_equal(x, y):
+                        diffs.append((sub, k, float(np.abs(x - y).max())))
+            bad += bool(diffs)
+            print(i, "two ranks", "same" if not diffs else diffs, flush=True)
+        print("mismatches", bad)
+    sys.exit(0)
 if smoke:
     # the smoke entry script (Unet3D denoisers: conv3w / conv3f3c, fused attention, panel / tile implicit GEMM, stem): two ranks on one
     # GPU against one rank, the test's arguments; every rank prints the gathered metrics
