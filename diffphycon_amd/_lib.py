@@ -95,6 +95,7 @@ _SIGNATURES = {
     "dpc_unet3d_set_range_check": (C.c_int, [_P, _I]),
     "dpc_unet3d_range_status": (C.c_int, [_P, _I, _P]),
     "dpc_train_range_status": (C.c_int, [_I, _P]),
+    "dpc_selftest_fp16_clamp": (C.c_int, [_P, _P, _I, _P]),
     "dpc_profile_begin": (C.c_int, []),
     "dpc_profile_begin_classes": (C.c_int, [C.c_char_p]),
     "dpc_profile_end": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

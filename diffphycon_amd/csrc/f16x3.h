@@ -17,6 +17,21 @@ __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
 }
 __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
 
+// Hardware saturation (r04): with MODE.FP16_OVFL set (hwreg MODE bit 23) an fp16 RESULT that overflows is clamped to +-65504 instead of
+// becoming inf, so the v_med3 in front of every operand conversion (one of the ~four VALU instructions a split element costs next to
+// the MFMAs: DESIGN.md 6.1c) is not needed.  A kernel calls hw_sat_enable() once at its top and then uses sat16h / split_acc_h, which
+// are the identity / unsaturated forms under DPC_FP16_OVFL (default) and the software clamp otherwise (A/B: -DDPC_FP16_OVFL=0).
+// In range the results are bit-identical; beyond it (outside the f16x3 contract, watched by the range sentinel) hi = +-65504 either
+// way and the remainder plane holds f16(x - hi) instead of 0.  dpc_selftest_fp16_clamp (api.hip) checks the mode bit on the device.
+#ifndef DPC_FP16_OVFL
+#define DPC_FP16_OVFL 1
+#endif
+constexpr bool HW_SAT = DPC_FP16_OVFL != 0;
+__device__ __forceinline__ void hw_sat_enable() {
+    if (HW_SAT) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);        // hwreg(HW_REG_MODE, offset 23, width 1) = 1
+}
+__device__ __forceinline__ float sat16h(float x) { return HW_SAT ? x : sat16(x); }
+
 // 8 floats (already scaled and inside +-65504) -> two f16x8 planes (plane 0 = leading term)
 __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
                                        f16x8 (&o)[2]) {
@@ -39,6 +54,9 @@ __device__ __forceinline__ void split_acc(const f32x16& v, float mul, f16x8 (&o)
     split8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], o[0]);
     split8(t[8], t[9], t[10], t[11], t[12], t[13], t[14], t[15], o[1]);
 }
+
+template <bool SAT>
+__device__ __forceinline__ void split_acc_h(const f32x16& v, float mul, f16x8 (&o)[2][2]) { split_acc<SAT && !HW_SAT>(v, mul, o); }
 
 __device__ __forceinline__ void mfma3(f32x16& acc, const f16x8 (&a)[2], const f16x8 (&b)[2]) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);      // small terms first

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
     const long long img = blockIdx.x;
     const int N = p.N;
     const int ntiles = (N + 31) / 32;
+    hw_sat_enable();                                           // (f16x3.h: operand conversions saturate in hardware)
 
     // ---- one-time fill of the weight regions
     for (int q = tid; q < A_BYTES / 16; q += 512) {            // k | v parts of each head: 16 KB per head
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
                 n[q] = (xr[ks][q] - mean) * inv * g * SX;          // a masked token has x = mean = 0: stays exactly 0
             }
-            split8(sat16(n[0].x), sat16(n[0].y), sat16(n[0].z), sat16(n[0].w), sat16(n[1].x), sat16(n[1].y), sat16(n[1].z),
-                   sat16(n[1].w), xs[ks]);
+            split8(sat16h(n[0].x), sat16h(n[0].y), sat16h(n[0].z), sat16h(n[0].w), sat16h(n[1].x), sat16h(n[1].y), sat16h(n[1].z),
+                   sat16h(n[1].w), xs[ks]);
         }
     };
 
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ctxT[hd][r] *= alpha;
                 f16x8 vs[2][2], es[2][2];
-                split_acc<true>(vv, PROJ_DESCALE * SV, vs);
-                split_acc<false>(kk, SP, es);
+                split_acc_h<true>(vv, PROJ_DESCALE * SV, vs);
+                split_acc_h<false>(kk, SP, es);
                 mfma3(ctxT[hd], vs[0], es[0]);                 // ctx^T[e][d]: lane = d, regs = e
                 mfma_keep(ctxT[hd], wk[KS - 1][0], wk[KS - 1][1]);
                 mfma3(ctxT[hd], vs[1], es[1]);
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             for (int r = 0; r < 16; ++r) oT[r] = 0.f;
             f16x8 qs[2][2];
             {
-                split_acc<false>(qT, (qscale * SQ) / sum, qs);
+                split_acc_h<false>(qT, (qscale * SQ) / sum, qs);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     f16x8 cf[2];
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             }
             {
                 f16x8 os[2][2];
-                split_acc<true>(oT, SO / (SC * SQ), os);
+                split_acc_h<true>(oT, SO / (SC * SQ), os);
                 f16x8 wo[2 * NTC][2];
 #pragma unroll
                 for (int g = 0; g < 2 * NTC; ++g) {             // group g = (column tile g / 2, k-step g % 2)

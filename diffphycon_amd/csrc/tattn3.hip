@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int loff = l31 * 32 + hh * 16;
     const int F = p.F;
+    hw_sat_enable();                                   // (f16x3.h: operand conversions saturate in hardware)
 
     // ---- one-time fill: weight images verbatim, rotary / bias tables with padded rows
     for (int q = tid; q < QKV_RES / 16; q += 512)
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
                     n[q] = (xr[ks][q] - mean) * inv * g * SX;      // a masked token has x = mean = 0: stays exactly 0
                 }
-                split8(sat16(n[0].x), sat16(n[0].y), sat16(n[0].z), sat16(n[0].w), sat16(n[1].x), sat16(n[1].y),
-                       sat16(n[1].z), sat16(n[1].w), xs[ks]);
+                split8(sat16h(n[0].x), sat16h(n[0].y), sat16h(n[0].z), sat16h(n[0].w), sat16h(n[1].x), sat16h(n[1].y),
+                       sat16h(n[1].z), sat16h(n[1].w), xs[ks]);
             }
         }
         // ---- prefetch the next pixel's rows (consumed at the top of the next iteration)
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             f16x8 qs[2][2];
             {
                 f16x8 kk[2][2];
-                split_acc<true>(qT, 1.f, qs);
-                split_acc<true>(kT, 1.f, kk);
+                split_acc_h<true>(qT, 1.f, qs);
+                split_acc_h<true>(kT, 1.f, kk);
                 mfma3(st, kk[0], qs[0]);
                 mfma3(st, kk[1], qs[1]);
             }
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             f16x8 ps[2][2];
             {
                 f16x8 vs[2][2];
-                split_acc<true>(vv, PROJ_DESCALE * SV, vs);
-                split_acc<false>(st, SP, ps);
+                split_acc_h<true>(vv, PROJ_DESCALE * SV, vs);
+                split_acc_h<false>(st, SP, ps);
                 mfma3(oT, vs[0], ps[0]);
                 mfma_keep(oT, qs[0][0], qs[0][1]);
                 mfma3(oT, vs[1], ps[1]);
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             //      normalisation, the descale of P and V and the pre-scale of O are one multiplier
             {
                 f16x8 os[2][2];
-                split_acc<true>(oT, (SO / (SP * SV)) / l, os);
+                split_acc_h<true>(oT, (SO / (SP * SV)) / l, os);
                 f16x8 wo[2 * NTC][2];
 #pragma unroll
                 for (int g = 0; g < 2 * NTC; ++g) {                 // group g = (column tile g / 2, k-step g % 2)
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int loff = l31 * 32 + hh * 16;
     const int F = p.F;
+    hw_sat_enable();
 
     for (int q = tid; q < QKV_RES / 16; q += 256)
         reinterpret_cast<uint4*>(smem3)[q] = reinterpret_cast<const uint4*>(wq3 + (size_t)HD0 * HEAD_QKV)[q];
@@ -463,8 +465,8 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
                     n[q] = (xr[ks][q] - mean) * inv * g * SX;
                 }
-                split8(sat16(n[0].x), sat16(n[0].y), sat16(n[0].z), sat16(n[0].w), sat16(n[1].x), sat16(n[1].y),
-                       sat16(n[1].z), sat16(n[1].w), xs[T][ks]);
+                split8(sat16h(n[0].x), sat16h(n[0].y), sat16h(n[0].z), sat16h(n[0].w), sat16h(n[1].x), sat16h(n[1].y),
+                       sat16h(n[1].z), sat16h(n[1].w), xs[T][ks]);
             }
         }
 
@@ -495,8 +497,8 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
                 rotary(kT[T], T, PROJ_DESCALE * SQK);
-                split_acc<true>(kT[T], 1.f, kk[T]);
-                split_acc<true>(vv[T], PROJ_DESCALE * SV, vs[T]);
+                split_acc_h<true>(kT[T], 1.f, kk[T]);
+                split_acc_h<true>(vv[T], PROJ_DESCALE * SV, vs[T]);
             }
         };
         // query tile `it` of head hd against both key tiles; adds its to_out contribution to y
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
             f32x16 st[2];
             f16x8 qs[2][2];
             {
-                split_acc<true>(qT, 1.f, qs);
+                split_acc_h<true>(qT, 1.f, qs);
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
             f16x8 ps[2][2][2];
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
-                split_acc<false>(st[jt], SP, ps[jt]);
+                split_acc_h<false>(st[jt], SP, ps[jt]);
                 mfma3(oT, vs[jt][0], ps[jt][0]);
                 if (jt == 0) mfma_keep(oT, qs[0][0], qs[0][1]);
                 else mfma_keep(oT, ps[0][0][0], ps[0][0][1]);
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                 else mfma_keep(oT, ps[0][1][0], ps[0][1][1]);
             }
             f16x8 os[2][2];
-            split_acc<true>(oT, (SO / (SP * SV)) / l, os);
+            split_acc_h<true>(oT, (SO / (SP * SV)) / l, os);
             f16x8 wo[2 * NTC][2];
 #pragma unroll
             for (int g = 0; g < 2 * NTC; ++g) {                     // group g = (column tile g / 2, k-step g % 2)
@@ -718,4 +720,25 @@ int launch_tattn3(const TattnParams& p_in, const unsigned char* wq3, const unsig
     return DPC_OK;
 }
 
+// ---- device self-test of the hardware saturation the fused attention kernels rely on (f16x3.h: hw_sat_enable)
+__global__ void fp16_clamp_selftest_kernel(const float* __restrict__ x, float* __restrict__ out, int n) {
+    hw_sat_enable();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const unsigned hi = cvt_pk(v, 0.f);
+    const unsigned lo = f16_sub_pk(v, 0.f, hi);
+    out[2 * i] = (float)__builtin_bit_cast(f16x2, hi).x;
+    out[2 * i + 1] = (float)__builtin_bit_cast(f16x2, lo).x;
+}
+
 }  // namespace dpc
+
+extern "C" int dpc_selftest_fp16_clamp(const float* x, float* out, int n, dpc_stream_t stream) {
+    using namespace dpc;
+    DPC_REQUIRE(x && out && n >= 0, "selftest_fp16_clamp: bad argument");
+    if (n == 0) return DPC_OK;
+    hipLaunchKernelGGL(fp16_clamp_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}

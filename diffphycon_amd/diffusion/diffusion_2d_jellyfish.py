@@ -288,9 +288,17 @@ class GaussianDiffusion(nn.Module):
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         batch_size = cond[0].shape[0]
         self._draw = _begin_noise_epoch(self)
-        return sample_fn((batch_size, frames, channels, image_size, image_size), design_fn, design_guidance,
-                         return_all_timesteps=return_all_timesteps, cond=cond, thetas_0=thetas_0, bd_updater=bd_updater,
-                         device=device)
+        out = sample_fn((batch_size, frames, channels, image_size, image_size), design_fn, design_guidance,
+                        return_all_timesteps=return_all_timesteps, cond=cond, thetas_0=thetas_0, bd_updater=bd_updater,
+                        device=device)
+        # ONE host read per sample(): the f16x3 range sentinels of the two denoisers and the watched window of the design gradient's
+        # backward convolutions (model/surrogates_hip.py: _Calibration) -- results that left the window fail here, loudly
+        for m in (self.model_states, self.model_thetas):
+            if hasattr(m, "check_range"):
+                m.check_range()
+        if hasattr(design_fn, "check_range"):
+            design_fn.check_range()
+        return out
 
 
 class Trainer(object):

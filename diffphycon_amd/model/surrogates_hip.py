@@ -21,7 +21,6 @@ import os
 import torch
 
 from .. import _lib
-from ..parallel import max_scalar_over_ranks
 
 # arithmetic of the convolutions: "f16x3" (default; 22-bit operands, 3 MFMAs per product, the 3x3 convs on the LDS halo-tile
 # kernel), "x6" (bf16x6: fp32-equivalent products, 6 MFMAs, implicit GEMM only) or "f32"
@@ -29,19 +28,27 @@ _MODE = os.environ.get("DPC_SURROGATE_MODE", "f16x3")
 
 
 class _Calibration:
-    """Range calibration of the backward pass.  The f16x3 operand split represents an activation to <= 2^-22 of its own
-    magnitude only inside [~1e-2, 4094] (absolute floor 2e-9, clamp above); forward activations sit there by construction
-    (every conv input is GroupNorm / LayerNorm / softmax output), gradients do not -- through the two nets the per-tensor
-    maximum spans 1e-9 .. 1e-1.  The backward convolutions therefore carry a per-convolution power-of-two operand scale
-    (dpc_conv_run's act_scale, undone in the epilogue).  While a calibration is active every backward convolution measures
-    max |input| (one streaming pass + a host read) and sets its scale so that the maximum lands on `target`; between
-    calibrations (every DPC_SURROGATE_RANGE_CHECK_EVERY design-gradient calls, default 64) the scales are reused: a tensor may
-    grow 8 x before it meets the clamp and shrink ~1e4 x before the tolerance notices.  With several ranks the measured maxima
-    are MAX-reduced over the ranks (parallel.max_scalar_over_ranks: one float per convolution per calibration), so the scales --
-    and with them every trajectory's bits -- do not depend on how the batch is sharded."""
-    target = 512.0
-    active = False
+    """Range calibration of the backward pass.  The f16x3 operand split represents an element to 2^-22 of ITS OWN magnitude while
+    |x * scale| lies in [2^-3, 65504] and to an absolute 2^-25 / scale below (fp16 subnormals of the remainder plane): with the
+    tensor's maximum placed at `target` = 16 the floor is 2e-9 of that maximum and the clamp 4 000 x above it.  Forward activations
+    sit in the window by construction (every conv input is a GroupNorm / LayerNorm / softmax output); gradients do not -- through
+    the two nets the per-tensor maximum spans 1e-9 .. 1e-1 -- so every backward-data convolution carries a per-convolution
+    power-of-two operand scale (dpc_conv_run's act_scale, undone in its epilogue; a power of two moves no mantissa bit).
+
+    r04: the scales are fixed ONCE, before the first design-gradient call, on a SYNTHETIC seeded input of one trajectory (the
+    activations of both nets are normalised, so the gradient magnitudes depend on the weights and the geometry, hardly on the data:
+    profiles/r04_calibration_drift.log) -- a set-up step like the weight packing, with its host reads outside the sampling loop.
+    Every rank computes the same scales from the same seeded input: nothing is exchanged, and a trajectory's bits do not depend on how
+    the batch is sharded or chunked.  (r03 re-measured max |input| on the live batch every 64 calls: one host sync and one
+    all-reduce(MAX) per convolution inside the loop.)  Inside the loop the window is only WATCHED, on the device: every
+    DPC_SURROGATE_RANGE_CHECK_EVERY calls (default 64) each backward convolution folds max |input| into a device-resident running peak
+    (one streaming pass, no sync); `HipDesignGradient.check_range()` -- called once at the end of `sample()` -- reads the peaks and
+    raises if one reached the clamp."""
+    target = 16.0
+    active = False      # calibrating: measure, read back, set the scale (set-up only)
+    watch = False       # inside the loop: fold max |input| into the convolution's device-resident peak
     seen = []           # (max |input|, scale) per calibrated convolution of the last calibration pass
+    convs = None        # weak set of the dynamic convolutions (check_range walks it)
 
 
 def _f(t):
@@ -55,6 +62,11 @@ class _Conv:
         w = _f(w)
         self.dynamic = dynamic and (mode or _MODE) == "f16x3"
         self.act_scale = 0.0
+        if self.dynamic:
+            import weakref
+            if _Calibration.convs is None:
+                _Calibration.convs = weakref.WeakSet()
+            _Calibration.convs.add(self)
         self.N, self.K, self.kh, self.kw = w.shape
         self.sh, self.sw = sh, sw
         ph = (self.kh - 1) // 2 if ph is None else ph
@@ -78,16 +90,20 @@ class _Conv:
         Wo = Wi if Wo is None else Wo
         C0 = a0.shape[-1] if C0 is None else C0
         C1 = a1.shape[-1] if a1 is not None else 0
-        if self.dynamic and _Calibration.active:
+        if self.dynamic and (_Calibration.active or _Calibration.watch):
             m = torch.zeros(1, device=a0.device)
             _lib.check(_lib.lib().dpc_absmax(_lib.ptr(a0), a0.numel(), _lib.ptr(m), _lib.stream()))
-            m = max_scalar_over_ranks(float(m.item()), a0.device)          # same scales on every rank as one process would pick
-            if not math.isfinite(m):
-                raise RuntimeError("design gradient: a backward tensor of the surrogate nets is not finite (Inf / NaN reached the "
-                                   "range calibration of a backward-data convolution)")
-            if m > 0:
-                self.act_scale = 2.0 ** max(-100, min(100, round(math.log2(_Calibration.target / m))))
-            _Calibration.seen.append((m, self.act_scale))
+            if _Calibration.active:                                  # set-up pass on the synthetic input: host read allowed
+                m = float(m.item())
+                if not math.isfinite(m):
+                    raise RuntimeError("design gradient: a backward tensor of the surrogate nets is not finite (Inf / NaN reached "
+                                       "the range calibration of a backward-data convolution)")
+                if m > 0:
+                    self.act_scale = 2.0 ** max(-100, min(100, round(math.log2(_Calibration.target / m))))
+                _Calibration.seen.append((m, self.act_scale))
+                self.peak = None
+            else:                                                    # in the loop: device-side running maximum, no sync
+                self.peak = m if getattr(self, "peak", None) is None else torch.maximum(self.peak, m)
         if out is None:
             rows = images * (Ho * Wo if out_mode != 2 else 4 * Ho * Wo)
             out = torch.empty(rows, self.N, device=a0.device, dtype=torch.float32)
@@ -694,25 +710,54 @@ class HipDesignGradient:
         self.calibrated = _MODE == "f16x3"            # per-convolution operand scales of the backward pass (_Calibration)
         self.check_every = int(os.environ.get("DPC_SURROGATE_RANGE_CHECK_EVERY", "64"))
         self.calls = 0
-        self.last_calibration = None
+        self.last_calibration = None                  # [(max |input| on the synthetic input, scale)] of the set-up pass
+        self._calibrated_for = None                   # (T, Cd, H, W) the scales were fixed for
 
     # largest activation of the two nets: the level-0 tensors [B T H W, dim] fp32 (dim = image_size, inference_2d_jellyfish.py
     # load_model).  The kernels address a tensor with 32-bit BYTE offsets inside buffer descriptors: keep every tensor below 2 GB.
     _MAX_TENSOR_BYTES = 3 << 29                 # 1.6 GB (measured: 1.34 GB tensors run, 2.68 GB fault)
 
+    def calibrate(self, T, Cd, H, W, device):
+        """Fix the operand scales of the backward-data convolutions on a seeded synthetic trajectory (see _Calibration): uniform
+        [-1, 1] states, a constant theta map, a random boundary mask -- the same tensors on every rank.  Set-up, not loop, work."""
+        g = torch.Generator().manual_seed(20240229)
+        x = torch.rand(1, T, Cd, H, W, generator=g) * 2 - 1
+        x[:, :, -1 if self.only_p else 3] = 0.3
+        bd = (torch.rand(1, 1, 3, H, W, generator=g) > 0.7).float().expand(-1, T, -1, -1, -1).contiguous()
+        self._run(x.to(device), bd.to(device), "calibrate")
+        self._calibrated_for = (T, Cd, H, W)
+
+    def check_range(self):
+        """One host read per sample() call: did a backward tensor reach the fp16 clamp of its convolution since the last check?"""
+        convs = [c for c in (_Calibration.convs or ()) if getattr(c, "peak", None) is not None and c.act_scale > 0]
+        if not convs:
+            return None
+        peaks = torch.cat([c.peak for c in convs]).cpu().tolist()
+        worst = max(p * c.act_scale for p, c in zip(peaks, convs))
+        for c in convs:
+            c.peak = None
+        self.last_headroom = 65504.0 / worst if worst > 0 else float("inf")      # x by which the largest watched tensor could still grow
+        if not math.isfinite(worst) or worst > 65504.0:
+            raise RuntimeError(f"design gradient: a backward tensor left the fp16 window of its convolution (max |x| * scale = {worst:.3g} "
+                               "> 65504; scales were fixed on the synthetic calibration input): call calibrate() on representative "
+                               "data or set DPC_SURROGATE_MODE=x6")
+        return self.last_headroom
+
     def __call__(self, x, bd_0):
-        check = self.calibrated and (self.calls == 0 or (self.check_every > 0 and self.calls % self.check_every == 0))
+        B, T, Cd_, H, W = x.shape
+        if self.calibrated and self._calibrated_for != (T, Cd_, H, W):
+            self.calibrate(T, Cd_, H, W, x.device)
+        check = "watch" if (self.calibrated and self.check_every > 0 and self.calls % self.check_every == 0) else None
         self.calls += 1
-        B, T, _, H, W = x.shape
         per_traj = T * H * W * max(self.force.mid // 8, 64) * 4            # bytes of a level-0 activation per trajectory (dim = mid / 8)
         chunk = max(1, self._MAX_TENSOR_BYTES // per_traj)
         if B <= chunk:
             return self._run(x, bd_0, check)
         # J128 at 16 trajectories per GPU (128 x 128 x 20 frames, dim 128): the level-0 activations would be 2.7 GB -> the batch is
-        # processed in chunks of <= `chunk` trajectories (they are independent); the range calibration runs on the first chunk
+        # processed in chunks of <= `chunk` trajectories (they are independent; the operand scales are fixed, so chunking changes no bit)
         outs = []
         for b0 in range(0, B, chunk):
-            outs.append(self._run(x[b0:b0 + chunk].contiguous(), bd_0[b0:b0 + chunk].contiguous(), check and b0 == 0))
+            outs.append(self._run(x[b0:b0 + chunk].contiguous(), bd_0[b0:b0 + chunk].contiguous(), check))
         return torch.cat(outs, dim=0)
 
     def _run(self, x, bd_0, check):
@@ -730,15 +775,15 @@ class HipDesignGradient:
         self.last_force = force
         w = torch.arange(T, 0, -1, dtype=torch.float32, device=x.device)
         dforce = (-(w / T)).repeat(B).reshape(n, 1).contiguous()
-        _Calibration.active, _Calibration.seen = check, []
+        _Calibration.active, _Calibration.watch, _Calibration.seen = check == "calibrate", check == "watch", []
         try:
             d_inp = self.force.backward(dforce)
             out = torch.zeros_like(x)
             _lib.check(L.dpc_cl_to_nchw(_lib.ptr(d_inp), _lib.ptr(out), n, 1, 4, 0, Cd, c_p, a, HW, S()))
             dts = self.unet.backward_theta(d_inp)
         finally:
-            _Calibration.active = False
-        if check:
+            _Calibration.active = _Calibration.watch = False
+        if check == "calibrate":
             self.last_calibration = list(_Calibration.seen)
         dtheta = self.unet.theta_grad(dts).reshape(B, T)
         th = theta.reshape(B, T)

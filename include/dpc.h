@@ -74,6 +74,10 @@ int dpc_profile_begin(void);
    its K steps with only the dominant class instrumented (4 % -> 0.4 % overhead). */
 int dpc_profile_begin_classes(const char* class_names);
 int dpc_profile_end(dpc_profile_row* rows, int max_rows, int* n_rows);
+/* Device self-test: the f16x3 operand split (hi = fp16(x), lo = fp16(x - hi)) of n floats exactly as the fused attention kernels
+ * evaluate it, i.e. with MODE.FP16_OVFL set so that an overflowing conversion SATURATES at +-65504 instead of producing inf
+ * (csrc/f16x3.h: hw_sat_enable -- those kernels dropped their software clamp in r04).  out[2 i] = hi, out[2 i + 1] = lo as floats. */
+int dpc_selftest_fp16_clamp(const float* x, float* out, int n, dpc_stream_t stream);
 
 /* ------------------------------------------------------------------ space-time U-Net denoiser
  * Replaces model/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py

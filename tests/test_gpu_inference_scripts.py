@@ -131,7 +131,7 @@ def test_jellyfish_script_two_ranks_match_single_rank(tmp_path):
             for sub in ("thetas", "states"):
                 a, b = np.load(tmp_path / "a" / sub / f"{i}.npy"), np.load(tmp_path / "b" / sub / f"{i}.npy")
                 # bit-equal: denoisers, update kernels and (r02) both surrogate nets forward + backward run on libdpc, whose kernels
-                # are batch invariant; the operand scales of the backward convolutions are calibrated on maxima shared by the ranks
+                # are batch invariant; the operand scales of the backward convolutions are fixed on a seeded synthetic input (r04): no exchange
                 if not np.array_equal(a, b):
                     bad.append((sub, i, float(np.abs(a - b).max())))
         return bad

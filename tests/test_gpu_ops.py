@@ -279,3 +279,21 @@ def test_philox_normal_sharding_invariance(dev, L):
     L.check(L.lib().dpc_philox_normal(L.ptr(big), 64, 65536, 7, 0, 0, L.stream()))
     assert abs(big.mean().item()) < 2e-3 and abs(big.std().item() - 1) < 2e-3
     assert abs((big ** 4).mean().item() - 3) < 0.05
+
+
+def test_hardware_fp16_saturation_of_the_operand_split(dev):
+    """The fused attention kernels (csrc/tattn3.hip, lattn3.hip) dropped the software clamp in front of the fp16 operand conversion in
+    r04 and set MODE.FP16_OVFL instead (csrc/f16x3.h: hw_sat_enable): an overflowing conversion must SATURATE at +-65504, never give inf.
+    In range the split is the exact 22-bit one: hi + lo == x to 2^-22 |x|, hi = fp16(x)."""
+    from diffphycon_amd import _lib as L
+    x = torch.tensor([0.0, 1.0, -3.25, 1234.567, 65504.0, 65519.9, 70000.0, -1.0e5, 1.0e6, -3.0e38, 4093.999, 6.1e-5], device=dev)
+    out = torch.empty(2 * x.numel(), device=dev)
+    L.check(L.lib().dpc_selftest_fp16_clamp(L.ptr(x), L.ptr(out), x.numel(), L.stream()))
+    hi, lo = out[0::2].cpu(), out[1::2].cpu()
+    xc = x.cpu()
+    assert torch.isfinite(out).all(), out                         # saturation, not inf
+    big = xc.abs() > 65504
+    assert torch.equal(hi[big], torch.sign(xc[big]) * 65504.0)
+    assert torch.equal(hi[~big], xc[~big].half().float())
+    assert ((hi + lo)[~big] - xc[~big]).abs().max() <= 2.0 ** -21 * xc[~big].abs().max()
+    assert torch.equal(lo[big], (xc[big] - hi[big]).clamp(-65504, 65504).half().float())
