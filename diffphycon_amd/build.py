@@ -9,12 +9,21 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdpc.so")
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar f32 adds / muls into v_pk_*_f32, which beside an MFMA stream costs more
 # issue time than the two scalar ops (r02: smoke step 303.7 -> 298.5 ms with the flag; MI355X_MICROARCH.md says the same)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# -packed-fp32-ops (r04): NO v_pk_{mul,add,fma}_f32 anywhere in the library.  With them, kernels gave wrong results in a few per cent of
+# launches whenever ANOTHER kernel was resident on the GPU at the same time (a second stream or a second process): r02 saw it in
+# ln_apply (`v_pk_mul_f32 ... op_sel` on a freshly loaded (mean, rstd) pair: wrong low lanes, worked around locally), r03 in the two-rank
+# entry-script tests (2 of 70 Burgers runs; attributed to an MFMA operand re-load), r04 pinned it down: the K = 32 qkv projection behind
+# a LayerNorm (the same (x - mean) * rstd * gamma expression in the implicit GEMM's prologue) next to a ConvTranspose on a second stream
+# -- 11 of 400 repetitions wrong in lanes 48..63, 0 of 400 with this flag; whole U-Net forwards on two streams 13 of 400 -> 0 of 400,
+# the 2-D net 3 of 400 -> 0 of 400 (tools/det_ops2.py, two_stream_bisect*.py; profiles/r04_packed_fp32_*.log).  No such
+# hazard is in the ISA guide; an idle GPU never shows it.  Speed: neutral (r03 A/B 265.1 vs 264.9 ms per S64 step; r04: profiles/).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # Kernels that must compile WITHOUT register spills: a spilling build of the 128-register implicit-GEMM kernel has (twice) given
 # batch-size dependent results at full size; the build fails instead of shipping one.
 # conv3w_kernel: its loader waves count their own vmcnt -- a compiler-inserted scratch reload there waits for every load in flight.
 NO_SPILL = {"igemm6.hip": ("igemm3_kernel",), "conv3w.hip": ("conv3w_kernel",), "igemm_wide.hip": ("igemm3w_kernel",),
-            "igemm_panel.hip": ("igemm3p_kernel",), "igemm_tile.hip": ("igemm3t_kernel",), "stem7x6.hip": ("stem7p_kernel",)}
+            "igemm_panel.hip": ("igemm3p_kernel",), "igemm_tile.hip": ("igemm3t_kernel",), "stem7x6.hip": ("stem7p_kernel",), "igemm_img.hip": ("igemm3i_kernel",)}
 
 
 def sources():

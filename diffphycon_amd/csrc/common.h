@@ -274,6 +274,9 @@ bool igemm3p_supported(const IgemmParams& p);
 bool igemm3t_supported(const IgemmParams& p);
 int launch_igemm3t(const IgemmParams& p, const void* wp6, hipStream_t s);
 int launch_igemm3p(const IgemmParams& p, const void* wp6, hipStream_t s);
+// pixel tiles with a K-block loop for 3 x 3 convolutions on small images with long reductions (igemm_img.hip); nsl as igemm3w
+bool igemm3i_supported(const IgemmParams& p);
+int launch_igemm3i(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s);
 bool igemm3w_supported(const IgemmParams& p);
 int igemm3w_slices(const IgemmParams& p);      // split-K slices by shape (N, reduction length), never by the batch
 int launch_igemm3w(const IgemmParams& p, const void* wp6, int nsl, hipStream_t s);

@@ -570,9 +570,10 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
         static const int split_ok = debug_switch("DPC_IGEMM_SPLITK", 1);
         const long long nwg = (long long)mtiles * (p.Npad / 64);
         const int nit = p.ntaps * p.kchunks;
-        const bool lds_b = igemm3w_supported(p);                     // 256 x 128 tiles, both operands through LDS (igemm_wide.hip)
+        const bool img = igemm3i_supported(p);                       // 3 x 3 on small images: unique pixels staged once per channel block (igemm_img.hip)
+        const bool lds_b = !img && igemm3w_supported(p);             // 256 x 128 tiles, both operands through LDS (igemm_wide.hip)
         int nsl = 1;
-        if (lds_b) nsl = split_ok ? igemm3w_slices(p) : 1;
+        if (img || lds_b) nsl = split_ok ? igemm3w_slices(p) : 1;
         else if (split_ok && !wide && p.out_mode == 0 && !p.ln_stats && !p.gn_raw && p.N % 4 == 0 && nit >= 128) nsl = 4;
         DPC_REQUIRE(!p.gn_raw || (p.out_mode == 0 && !wide && p.N % 4 == 0 && p.gn_rows % 128 == 0),
                     "igemm3: fused GroupNorm residual needs out_mode 0, N % 4 == 0, rows per sample % 128 == 0");
@@ -583,7 +584,9 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
             IgemmParams q = p;
             q.ksplit = nsl;
             q.part = scratch;
-            if (lds_b) {
+            if (img) {
+                if (int rc = launch_igemm3i(q, wp6, nsl, s)) return rc;
+            } else if (lds_b) {
                 if (int rc = launch_igemm3w(q, wp6, nsl, s)) return rc;
             } else {
                 hipLaunchKernelGGL((igemm3_kernel<64, false>), dim3((unsigned)nwg, nsl), dim3(256), lds3, s, q, (const unsigned char*)wp6);
@@ -595,6 +598,7 @@ int launch_igemm6(const IgemmParams& p_in, const void* wp6, hipStream_t s) {
             DPC_LAUNCH_CHECK();
             return DPC_OK;
         }
+        if (img) return launch_igemm3i(p, wp6, 1, s);
         if (lds_b) return launch_igemm3w(p, wp6, 1, s);
         const bool vec = (p.N & 3) == 0 && p.out_mode != 1;
         if (wide) {

@@ -6,6 +6,7 @@ restatement of the operator, on shapes chosen to land in each kernel and each of
   * pixel tiles (csrc/igemm_tile.hip): the stride-1 2 x 2-tap classes of ConvTranspose at 64 -> 64 and 128 -> 128 channels, plain
     and with the parity scatter (out_mode 2), every parity's tap offsets, images narrower than a tile;
   * LDS-tiled wide kernel (csrc/igemm_wide.hip): reductions of >= 24 chunks, 128- and 64-column tiles, split-K by N, K % 32 != 0;
+  * image tiles (csrc/igemm_img.hip, r04): the 3 x 3 convolutions of the Burgers net's 4 x 32 / 2 x 16 / 1 x 8 levels;
   * the narrow kernel (csrc/igemm6.hip) for what neither takes (shared vector epilogue, fragment-order weight pack).
 
 Every case has a RAGGED row count (M is not a multiple of 32 / 64 / 256) so the tail rows of the last tile are exercised, and is
@@ -80,13 +81,23 @@ CASES = [
     ("narrow 36->64 +res", 3, 5, 7, 36, 0, 64, (1, 1), (1, 1), (0, 0), True, False, None),
     ("narrow 64->192", 3, 5, 7, 64, 0, 192, (1, 1), (1, 1), (0, 0), False, False, None),
     ("narrow 3x3 64->64 (18 chunks)", 3, 5, 7, 64, 0, 64, (3, 3), (1, 1), (1, 1), True, False, None),
+    # ---- image tiles (r04, csrc/igemm_img.hip): 3 x 3 on images at most 32 wide that are not 8 x 8-tileable, >= 24 (tap, chunk) iterations,
+    #      N % 128 == 0: unique pixels staged once per 32-channel block; residual, concat, split-K by N, the 3-tap form of the H = 1 level,
+    #      tiles that hold exactly one image (4 x 32), several images (2 x 16) and straddle images (4 x 13)
+    ("img 3x3 256->256", 5, 4, 13, 256, 0, 256, (3, 3), (1, 1), (1, 1), True, False, None),
+    ("img 3x3 concat 128+128->128", 5, 4, 13, 128, 128, 128, (3, 3), (1, 1), (1, 1), False, False, None),
+    ("img 3x3 256->256, 4 x 32 images (one image per tile)", 3, 4, 32, 256, 0, 256, (3, 3), (1, 1), (1, 1), False, False, None),
+    ("img 3x3 concat 256+128->128, 2 x 16 images", 7, 2, 16, 256, 128, 128, (3, 3), (1, 1), (1, 1), True, False, None),
+    ("img 3x3 96->128 (3 blocks, the shortest reduction it takes)", 3, 3, 5, 96, 0, 128, (3, 3), (1, 1), (1, 1), False, False, None),
+    ("img 3x3 concat 104+24->128 (a block straddles the sources)", 4, 4, 11, 104, 24, 128, (3, 3), (1, 1), (1, 1), False, False, None),
     # ---- wide: >= 24 chunks.  128-column tiles, 64-column tiles, split-K by N (512: 2 slices, 1024: 4), K % 32 != 0, concat
-    ("wide 3x3 256->256", 5, 4, 13, 256, 0, 256, (3, 3), (1, 1), (1, 1), True, False, None),
-    ("wide 3x3 concat 128+128->128", 5, 4, 13, 128, 128, 128, (3, 3), (1, 1), (1, 1), False, False, None),
+    ("wide 3x3 256->256 (40-wide images)", 2, 3, 40, 256, 0, 256, (3, 3), (1, 1), (1, 1), True, False, None),
+    ("wide 3x3 concat 128+128->128 (40-wide images)", 2, 3, 40, 128, 128, 128, (3, 3), (1, 1), (1, 1), False, False, None),
     ("wide 3x3 100->64 (64-column tile, K % 32 != 0)", 5, 4, 13, 100, 0, 64, (3, 3), (1, 1), (1, 1), False, False, None),
     ("wide 4x4 s2 64->64 (down conv)", 3, 10, 14, 64, 0, 64, (4, 4), (2, 2), (1, 1), False, False, None),
-    ("wide 3x3 256->512 split 2", 5, 2, 9, 256, 0, 512, (3, 3), (1, 1), (1, 1), True, False, None),
-    ("wide 3x3 512->1024 split 4, 1 x 8 images (dead taps)", 7, 1, 8, 512, 0, 1024, (3, 3), (1, 1), (1, 1), False, False, None),
+    ("img 3x3 256->512 split 2", 5, 2, 9, 256, 0, 512, (3, 3), (1, 1), (1, 1), True, False, None),
+    ("img 3x3 512->1024 split 4, 1 x 8 images (dead taps: 3-tap form)", 7, 1, 8, 512, 0, 1024, (3, 3), (1, 1), (1, 1), False, False, None),
+    ("wide 3x3 256->512 split 2 (40-wide images)", 2, 2, 40, 256, 0, 512, (3, 3), (1, 1), (1, 1), True, False, None),
     ("wide 1x1 1024->512 split 2", 3, 5, 7, 1024, 0, 512, (1, 1), (1, 1), (0, 0), True, False, None),
 ]
 

@@ -21,6 +21,7 @@ FILES = {
     "igemm_panel.hip": ("igemm3p_kernel", 24),
     "igemm_tile.hip": ("igemm3t_kernel", 2),
     "igemm_wide.hip": ("igemm3w_kernel", 4),
+    "igemm_img.hip": ("igemm3i_kernel", 4),
     "stem7x6.hip": ("stem7", 5),
     "tattn3.hip": ("tattn3", 9),
     "lattn3.hip": ("lattn3_kernel", 2),
@@ -38,7 +39,12 @@ def test_no_lds_read_lands_in_a_b_operand_of_the_last_four_mfmas(src):
         pytest.skip("needs hipcc")
     import mfma_war_audit as A
     prefix, at_least = FILES[src]
-    ks = A.kernels(A.compile_asm(src))
+    asm = A.compile_asm(src)
+    # r04: the library is built WITHOUT packed fp32 VALU ops (diffphycon_amd/build.py: -packed-fp32-ops) -- with them a co-resident second
+    # kernel changed results in a few per cent of launches (tools/det_ops2.py); the audit compiles with the product flags
+    import re
+    assert not re.search(r"\bv_pk_(mul|add|fma)_f32\b", asm), f"{src}: packed fp32 VALU instructions in the ISA (build flags lost?)"
+    ks = A.kernels(asm)
     seen = 0
     for name, lines in ks.items():
         best, n_mfma = A.audit(lines)

@@ -24,6 +24,7 @@ CASES = {
     "void dpc::igemm3p_kernel<4, 1, 2, 2, 2, false, 64>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
     "void dpc::igemm3t_kernel<2, 4, 2, 1, 2, 2, 128>(dpc::IgemmParams, unsigned char const*)": "igemm_bn64",
     "void dpc::igemm3t_kernel<4, 4, 1, 2, 2, 2, 64>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
+    "void dpc::igemm3i_kernel<false, 9>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
     "void dpc::igemm3w_kernel<false, 64>(dpc::IgemmParams, unsigned char const*)": "igemm_bn64",
     "void dpc::igemm3w_kernel<true, 128>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
     "void dpc::stem7x6_kernel<true, 8>(dpc::StemParams, unsigned char const*)": "stem_gather",

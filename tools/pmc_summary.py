@@ -24,6 +24,7 @@ CLASSES = [
     (r"igemm3p_kernel<\d+, 1, 1, 2, 2", "igemm_bn64"), (r"igemm3p_kernel<", "igemm_bn128"),       # (row panels: N = 32 NT WN)
     (r"igemm3w_kernel<(true|false), 64>", "igemm_bn64"), (r"igemm3w_kernel<", "igemm_bn128"),
     (r"igemm3t_kernel<2,", "igemm_bn64"), (r"igemm3t_kernel<", "igemm_bn128"),                      # (pixel tiles: 64 -> 64 / 128 -> 128)
+    (r"igemm3i_kernel<", "igemm_bn128"),                                                           # (image tiles: N % 128 == 0)
     (r"igemm[63]?_kernel<128", "igemm_bn128"), (r"igemm[63]?_kernel<64|conv1x1_rows_kernel", "igemm_bn64"),
     (r"stem7x6_kernel|stem7p_kernel|stem_kernel", "stem_gather"), (r"tattn(_fused|6|3w?)_kernel", "temporal_attention_fused"),
     (r"lattn(3|6?_(ctx|out))_kernel", "linear_attention_fused"), (r"gn_(partial|finalize|finalize_fused|apply)_kernel", "groupnorm_silu"),
@@ -37,8 +38,8 @@ CLASSES = [
 # profile class -> the kernel source file(s) whose code its default-mode launches run: the traffic numbers are stamped with a hash
 # of these files and bench.py reports `traffic: null` when the stamp no longer matches the tree (a changed kernel = stale counters)
 SOURCES = {
-    "conv3x6_bn64": ["conv3w.hip", "conv3f3c.hip"], "conv3x6_bn128": ["conv3w.hip", "conv3f3c.hip"], "igemm_bn64": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_epilogue.h"],
-    "igemm_bn128": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_epilogue.h"], "stem_gather": ["stem7x6.hip"], "temporal_attention_fused": ["tattn3.hip"],
+    "conv3x6_bn64": ["conv3w.hip", "conv3f3c.hip"], "conv3x6_bn128": ["conv3w.hip", "conv3f3c.hip"], "igemm_bn64": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_img.hip", "igemm_epilogue.h"],
+    "igemm_bn128": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_img.hip", "igemm_epilogue.h"], "stem_gather": ["stem7x6.hip"], "temporal_attention_fused": ["tattn3.hip"],
     "linear_attention_fused": ["lattn3.hip"], "groupnorm_silu": ["norm.hip"], "ln_stats": ["norm.hip"], "attention_core": ["attn.hip"],
     "ddpm_update": ["update.hip"], "conv3_wgrad_f16x3": ["wgrad3.hip"], "conv_wgrad": ["train.hip"], "attention_bwd": ["train.hip"],
 }
