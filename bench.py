@@ -69,6 +69,10 @@ def mfma_roof(kernel_class, modes):
     16-bit MFMAs per fp32 product."""
     md = dict(kv.split("=") for kv in modes.split(",")) if modes else {}
     mode = md.get(family_of(kernel_class), "f32")
+    if kernel_class == "conv3_wgrad_f16x3":           # the 3x3x3 weight gradient is always f16x3 (wgrad3.hip), the other geometries
+        mode = "f16x3"                                # ("conv_wgrad") exact fp32 products on the fp32 MFMA (train.hip)
+    elif kernel_class == "conv_wgrad":
+        mode = "f32"
     if mode == "f32":
         return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA dense"
     if mode == "x6":
@@ -454,7 +458,8 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
            "vs_baseline": None, "dtype": dtype_label(getattr(gd.model, "modes", "")), "data": "synthetic",
            "world_size_seen_by_rccl": ctx.seen_world,
            "arithmetic": f"forward {gd.model.modes if hasattr(gd.model, 'modes') else ''}; backward-data convolutions {bwd_mode}"
-                         f" (loss scale {loss_scale:g}); weight gradients exact fp32 products on the native fp32 MFMA",
+                         f" (loss scale {loss_scale:g}); weight gradients: 3x3x3 convolutions f16x3 (wgrad3.hip), every other geometry "
+                         "exact fp32 products on the native fp32 MFMA",
            "loss_first_last": [first, last],
            "config": {"workload": "S64 training step (SURVEY 8 f-4; scripts/smoke_train_joint.sh): Unet3D(dim 64, mults 1-2-4, 6 "
                                   f"channels) on 64x64 x 32 frames, batch={batch} per GPU, one optimizer step per bench step",

@@ -369,6 +369,7 @@ struct LattnParams {
     float* ctx;             // workspace [images][4][32][32]
     long long images;
     int N;
+    const float* gamma_out = nullptr;   // lattn3 only: gain of a channel LayerNorm behind to_out (2-D U-Net), nullptr = none
 };
 bool lattn_fused_supported(int C, int heads);
 size_t lattn_fused_workspace_bytes(long long images);

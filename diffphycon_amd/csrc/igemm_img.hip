@@ -40,6 +40,7 @@ constexpr int LDS = (NRMAX + 1) * PITCH;
 // NTAPS: 9, or 3 for the H = 1 level (the launcher of igemm6.hip drops the six taps that only ever see padding)
 template <bool SPLIT, int NTAPS>
 __global__ __launch_bounds__(256, 2) void igemm3i_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+    h3::hw_sat_enable();                               // (f16x3.h: operand conversions saturate in hardware)
     using namespace gi;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_i[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void igemm3i_kernel(IgemmParams p, const un
             if (g < ngroups) {
                 const f32x4 a = v[j][0] * p.act_scale, b = v[j][1] * p.act_scale;
                 h3::f16x8 pl[2];
-                h3::split8(h3::sat16(a.x), h3::sat16(a.y), h3::sat16(a.z), h3::sat16(a.w), h3::sat16(b.x), h3::sat16(b.y), h3::sat16(b.z),
-                           h3::sat16(b.w), pl);
+                h3::split8(h3::sat16h(a.x), h3::sat16h(a.y), h3::sat16h(a.z), h3::sat16h(a.w), h3::sat16h(b.x), h3::sat16h(b.y), h3::sat16h(b.z),
+                           h3::sat16h(b.w), pl);
                 unsigned char* dst = smem_i + (g >> 2) * PITCH + (g & 3) * 16;
                 *reinterpret_cast<h3::f16x8*>(dst) = pl[0];
                 *reinterpret_cast<h3::f16x8*>(dst + 64) = pl[1];

@@ -34,6 +34,7 @@ typedef _Float16 f16x8_p __attribute__((ext_vector_type(8)));
 // BM: panel rows (64; 32 for the 16-chunk im2col rows of the 128-channel ConvTranspose classes: 66 KB of LDS either way)
 template <int KC, int MT, int NT, int WM, int WN, bool TAPS, int BM>
 __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+    h3::hw_sat_enable();                               // (f16x3.h: operand conversions saturate in hardware)
     using namespace gpn;
     static_assert(WM * WN == 4 && WM * MT * 32 == BM, "four waves cover the panel");
     constexpr int KP = KC * 32;                                   // padded K
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void igemm3p_kernel(IgemmParams p, const un
         a = ok[j] ? a * p.act_scale : z;
         b = ok[j] ? b * p.act_scale : z;
         h3::f16x8 pl[2];
-        h3::split8(h3::sat16(a.x), h3::sat16(a.y), h3::sat16(a.z), h3::sat16(a.w), h3::sat16(b.x), h3::sat16(b.y), h3::sat16(b.z),
-                   h3::sat16(b.w), pl);
+        h3::split8(h3::sat16h(a.x), h3::sat16h(a.y), h3::sat16h(a.z), h3::sat16h(a.w), h3::sat16h(b.x), h3::sat16h(b.y), h3::sat16h(b.z),
+                   h3::sat16h(b.w), pl);
         unsigned char* dst = smem_p + row * PITCH + c * 2;
         *reinterpret_cast<h3::f16x8*>(dst) = pl[0];
         *reinterpret_cast<h3::f16x8*>(dst + KP * 2) = pl[1];

@@ -25,6 +25,7 @@ constexpr int RH = 80;                      // at most this many halo rows (max 
 // KCH: 32-channel chunks per tap (K = 32 KCH exactly); NTAPS taps; wave grid WM x WN, wave tile MT x NT blocks of 32 x 32
 template <int KCH, int NTAPS, int MT, int NT, int WM, int WN, int BM>
 __global__ __launch_bounds__(256, 2) void igemm3t_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+    h3::hw_sat_enable();                               // (f16x3.h: operand conversions saturate in hardware)
     static_assert(WM * WN == 4 && WM * MT * 32 == BM, "four waves cover the tile");
     constexpr int KP = KCH * 32;                                  // channels per pixel
     constexpr int PITCH = KP * 4 + 16;                            // bytes per LDS row: plane 0 (KP fp16) | plane 1 | pad (conflict-free b128 reads)
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256, 2) void igemm3t_kernel(IgemmParams p, const un
             const int row = g / GPR, c = (g % GPR) * 8;
             const f32x4 a = v[j][0] * p.act_scale, b = v[j][1] * p.act_scale;
             h3::f16x8 pl[2];
-            h3::split8(h3::sat16(a.x), h3::sat16(a.y), h3::sat16(a.z), h3::sat16(a.w), h3::sat16(b.x), h3::sat16(b.y), h3::sat16(b.z),
-                       h3::sat16(b.w), pl);
+            h3::split8(h3::sat16h(a.x), h3::sat16h(a.y), h3::sat16h(a.z), h3::sat16h(a.w), h3::sat16h(b.x), h3::sat16h(b.y), h3::sat16h(b.z),
+                       h3::sat16h(b.w), pl);
             unsigned char* dst = smem_t + row * PITCH + c * 2;
             *reinterpret_cast<h3::f16x8*>(dst) = pl[0];
             *reinterpret_cast<h3::f16x8*>(dst + KP * 2) = pl[1];

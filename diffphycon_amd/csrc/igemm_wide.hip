@@ -53,6 +53,7 @@ struct WStage {             // one chunk in flight: 2 activation rows x 8 channe
 // 64 columns): 8 waves as 8 x 1, 32 x 64 each
 template <bool SPLIT, int BN>
 __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+    h3::hw_sat_enable();                               // (f16x3.h: operand conversions saturate in hardware)
     using namespace gw;
     constexpr int BBYTES = BN * WROW, TAPOFF = 2 * (ABYTES + BBYTES);
     constexpr int MT = BN == 128 ? 2 : 1;                         // 32-row blocks per wave
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(512, 1) void igemm3w_kernel(IgemmParams p, const un
             const bool ok = st.ok >> i & 1;
             const f32x4 u = ok ? st.a[2 * i] * p.act_scale : z, v = ok ? st.a[2 * i + 1] * p.act_scale : z;
             h3::f16x8 pl[2];
-            h3::split8(h3::sat16(u.x), h3::sat16(u.y), h3::sat16(u.z), h3::sat16(u.w), h3::sat16(v.x), h3::sat16(v.y), h3::sat16(v.z),
-                       h3::sat16(v.w), pl);
+            h3::split8(h3::sat16h(u.x), h3::sat16h(u.y), h3::sat16h(u.z), h3::sat16h(u.w), h3::sat16h(v.x), h3::sat16h(v.y), h3::sat16h(v.z),
+                       h3::sat16h(v.w), pl);
             unsigned char* dst = A + (arow0 + 16 * i) * RS + acol * 2;
             *reinterpret_cast<h3::f16x8*>(dst) = pl[0];
             *reinterpret_cast<h3::f16x8*>(dst + 64) = pl[1];

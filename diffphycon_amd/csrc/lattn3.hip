@@ -2,6 +2,10 @@
 //   q,k,v = to_qkv(LayerNorm_c(x));  q = softmax_d(q) * s;  k = softmax_n(k);  ctx = k v^T;  out = ctx^T q;
 //   y = x + to_out(out) + b
 // Reference: video_diffusion_pytorch_conv3d.py:232-257 (SpatialLinearAttention), :441 (Residual(PreNorm(...))).
+// OUT_LN (r04): the 2-D U-Net's LinearAttention (model/burgers_1d/unet.py:188-229) is the same block with a channel LayerNorm behind
+// to_out (to_out = Sequential(Conv2d, LayerNorm), :196-199):  y = x + LayerNorm_c(to_out(out) + b) * g_out.  The token's C outputs
+// sit in the 32 lanes of a half-wave x NTC accumulator tiles, so the two reductions (mean, then the variance of the deviations --
+// the two-pass form of torch.var) are DPP adds inside the half-wave; nothing else changes.
 //
 // One 512-thread workgroup per frame image (N = H*W tokens).  All pre-split weights stay in LDS for the whole kernel:
 //   region A (64 KB): Wk | Wv of the four heads  -> after phase 1 reused as the cross-wave reduction scratch
@@ -41,7 +45,21 @@ constexpr float SP = 1024.f, SV = 16.f, SC = 16.f, SQ = 4096.f, SO = 16.f;
 
 __device__ __forceinline__ int rowmap_l3(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-template <int C_>
+// all-reduce over the 32 lanes that share lane >> 5 (fixed order: quad, 8, 16 by DPP, the two 16-lane rows by one ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum_half_wave(float v) {
+    v += dpp_f<0xB1>(v);               // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);               // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);              // row_half_mirror: the other quad of the 8
+    v += dpp_f<0x140>(v);              // row_mirror: the other 8 of the row
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+template <int C_, bool OUT_LN>
 __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const unsigned char* __restrict__ wq3,
                                                         const unsigned char* __restrict__ wo3) {
     using namespace l3;
@@ -339,10 +357,38 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                     for (int pl = 0; pl < 2; ++pl) wo_carry[i][pl] = wo[2 * NTC - 2 + i][pl];
             }
         }
-        // ---- bias + residual + store (lane = channel, regs = token)
+        // ---- bias (+ channel LayerNorm) + residual + store (lane = channel, regs = token)
+        float ln_mean[16], ln_inv[16];
+        if constexpr (OUT_LN) {
+            float sm_[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm_[r] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                const float bv = p.bout[nt * 32 + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    y[nt][r] = y[nt][r] * (1.f / (SO * SWGT)) + bv;
+                    sm_[r] += y[nt][r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ln_mean[r] = sum_half_wave(sm_[r]) / (float)C;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm_[r] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = y[nt][r] - ln_mean[r];
+                    sm_[r] += d * d;
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ln_inv[r] = 1.0f / sqrtf(sum_half_wave(sm_[r]) / (float)C + 1e-5f);
+        }
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
-            const float bv = p.bout[nt * 32 + l31];
+            const float bv = OUT_LN ? p.gamma_out[nt * 32 + l31] : p.bout[nt * 32 + l31];
             float res[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -352,7 +398,9 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nn = t * 32 + rowmap_l3(r, hh);
-                if (nn < N) p.out[(img * N + nn) * C + nt * 32 + l31] = (y[nt][r] * (1.f / (SO * SWGT)) + bv) + res[r];
+                if (nn >= N) continue;
+                if constexpr (OUT_LN) p.out[(img * N + nn) * C + nt * 32 + l31] = (y[nt][r] - ln_mean[r]) * ln_inv[r] * bv + res[r];
+                else p.out[(img * N + nn) * C + nt * 32 + l31] = (y[nt][r] * (1.f / (SO * SWGT)) + bv) + res[r];
             }
         }
     }
@@ -370,12 +418,20 @@ int launch_lattn3(const LattnParams& p, const unsigned char* wq3, const unsigned
                    4.0 * rows * C * 3, s);
     static DeviceOnce once;
     if (!once) {
-        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<64>::LDS_BYTES));
-        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<128>::LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<64>::LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<128>::LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<64>::LDS_BYTES));
+        DPC_HIP(hipFuncSetAttribute((const void*)lattn3_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, L3<128>::LDS_BYTES));
         once = true;
     }
-    if (C == 64) hipLaunchKernelGGL(lattn3_kernel<64>, dim3((unsigned)p.images), dim3(512), L3<64>::LDS_BYTES, s, p, wq3, wo3);
-    else hipLaunchKernelGGL(lattn3_kernel<128>, dim3((unsigned)p.images), dim3(512), L3<128>::LDS_BYTES, s, p, wq3, wo3);
+    const dim3 grid((unsigned)p.images), block(512);
+    if (p.gamma_out) {                // trailing channel LayerNorm (2-D U-Net)
+        if (C == 64) hipLaunchKernelGGL((lattn3_kernel<64, true>), grid, block, L3<64>::LDS_BYTES, s, p, wq3, wo3);
+        else hipLaunchKernelGGL((lattn3_kernel<128, true>), grid, block, L3<128>::LDS_BYTES, s, p, wq3, wo3);
+    } else {
+        if (C == 64) hipLaunchKernelGGL((lattn3_kernel<64, false>), grid, block, L3<64>::LDS_BYTES, s, p, wq3, wo3);
+        else hipLaunchKernelGGL((lattn3_kernel<128, false>), grid, block, L3<128>::LDS_BYTES, s, p, wq3, wo3);
+    }
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
         // r02: with the (mean, rstd) pair used straight from its dwordx2 load the compiler folds the broadcast of rstd into
         // `v_pk_mul_f32 ..., v[m:m+1] op_sel:[0,1]`, and that form gave wrong LOW lanes (components 0 / 2 of a row's float4s;
         // results like (v - mean) * 0) in ~5 % of launches whenever a second process kept the GPU busy -- never on an idle GPU,
-        // and never once rstd sits in a register of its own (tools/det_ops.py: 0 of 300 launches vs 11 of 200).  Cause not
-        // established (no such hazard in the ISA guide); the copy costs one VALU op per float4.
+        // and never once rstd sits in a register of its own (tools/det_ops.py: 0 of 300 launches vs 11 of 200).  r04 found the
+        // same failure in every packed fp32 op of the library whenever a second kernel is resident and builds
+        // without them (-packed-fp32-ops); the two copies stay as they are (one VALU op per float4).
         asm volatile("v_mov_b32 %0, %0" : "+v"(rstd));
         asm volatile("v_mov_b32 %0, %0" : "+v"(mean));
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);

@@ -29,7 +29,12 @@ namespace dpc {
 // A wave owns RA row fragments x RB column fragments (32 output channels each) = RA RB accumulator tiles, walks its slab of
 // (b, f, ho) rows two points at a time with a one-step register prefetch, and stores its partial sums; a second kernel adds the
 // slabs in fixed order and scatters into the reference weight layout.  Exact fp32 products, fp32 accumulation.
-constexpr int WG_RA = 4, WG_RB = 2;
+// r04: (a) the loads of step q + 4 are issued while step q is multiplied (a ring of four static register stages: a step is 8 MFMAs =
+// 0.2 us of matrix-pipe time, far less than a global-memory round trip, and a 128-accumulator wave has one or two neighbours on its
+// SIMD to hide it: the one-step prefetch of r03 ran at 0.27 of the fp32 roof); (b) a wave's 8 accumulator tiles are RA x RB = 4 x 2, or
+// 2 x 4 when the operand has only two row fragments (the 64-channel 1x1 projections: half of the 4 x 2 form's MFMAs multiplied
+// fragments that do not exist).  Per-accumulator summation order is unchanged.
+constexpr int WG_DEPTH = 4;
 
 struct WgradParams {
     const float* x;
@@ -50,6 +55,7 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
 
+template <int WG_RA, int WG_RB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -92,21 +98,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
     __amdgpu_buffer_rsrc_t ra[WG_RA], rb;
-    auto setup_row = [&](long long row) {
-        const int ho = (int)(row % p.Ho);
-        const long long bf = row / p.Ho;
-        const int f = (int)(bf % p.F);
-        const long long b = bf / p.F;
+    // request cursor: row = (b, f, ho) as counters + the two row pointers, advanced by constant strides (a 64-bit division and a
+    // multiply chain per row advance, inlined once per ring stage, cost more code than the rest of the kernel)
+    int c_ho = (int)(row_begin % p.Ho), c_f = (int)((row_begin / p.Ho) % p.F);
+    const long long xrow = (long long)p.Wi * p.C, yrow = (long long)p.Wo * p.N;
+    const float* c_x = p.x + (((row_begin / p.Ho / p.F) * p.F + c_f) * p.Hi + (long long)c_ho * p.sh) * xrow;     // row (b, f, ho * sh)
+    const float* c_y = p.dy + row_begin * yrow;
+    long long dj[WG_RA];                     // fragment j reads the row (df - pf) frames and (dh - ph) rows away
+#pragma unroll
+    for (int j = 0; j < WG_RA; ++j) dj[j] = ((long long)(df[j] - p.pf) * p.Hi + (dh[j] - p.ph)) * xrow;
+    const long long x_next_f = (long long)(p.Hi - (p.Ho - 1) * p.sh) * xrow;     // from the last row of a frame to row 0 of the next
+    auto setup_row = [&]() {
 #pragma unroll
         for (int j = 0; j < WG_RA; ++j) {
-            const int fs = f + df[j] - p.pf, hs = ho * p.sh + dh[j] - p.ph;
+            const int fs = c_f + df[j] - p.pf, hs = c_ho * p.sh + dh[j] - p.ph;
             const bool ok = rf_ok[j] && (unsigned)fs < (unsigned)p.F && (unsigned)hs < (unsigned)p.Hi;
-            const float* base = p.x + ((b * p.F + (ok ? fs : 0)) * p.Hi + (ok ? hs : 0)) * (long long)p.Wi * p.C;
-            ra[j] = make_rsrc(base, ok ? xrow_bytes : 0u);
+            ra[j] = make_rsrc(ok ? c_x + dj[j] : p.x, ok ? xrow_bytes : 0u);
         }
-        rb = make_rsrc(p.dy + row * (long long)p.Wo * p.N, yrow_bytes);
+        rb = make_rsrc(c_y, yrow_bytes);
     };
-    float a_cur[WG_RA], b_cur[WG_RB], a_nxt[WG_RA], b_nxt[WG_RB];
+    auto next_row = [&]() {
+        c_y += yrow;
+        if (++c_ho == p.Ho) {
+            c_ho = 0;
+            c_x += x_next_f;                 // (frames of consecutive samples are contiguous: f wraps without a jump)
+            if (++c_f == p.F) c_f = 0;
+        } else {
+            c_x += (long long)p.sh * xrow;
+        }
+        setup_row();
+    };
+    float a_st[WG_DEPTH][WG_RA], b_st[WG_DEPTH][WG_RB];
     auto issue = [&](int pr, float (&a)[WG_RA], float (&b)[WG_RB]) {
 #pragma unroll
         for (int j = 0; j < WG_RA; ++j) a[j] = bload(ra[j], ea[j] + (unsigned)pr * astep);
@@ -117,26 +139,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
     };
     if (row_begin < row_end) {
-        long long row = row_begin;
+        // request cursor (row, pr) of step `req`; it runs WG_DEPTH steps ahead of the multiplications and stops at the last step
+        // (steps past the end re-request the last one: harmless, never multiplied)
         int pr = 0;
-        setup_row(row);
-        issue(0, a_cur, b_cur);
         const long long total = (row_end - row_begin) * npair;
-        for (long long q = 0; q < total; ++q) {
-            // request step q + 1 (the last step re-requests itself: harmless)
-            if (q + 1 < total) {
-                if (++pr == npair) { pr = 0; ++row; setup_row(row); }
+        long long req = 0;
+        auto advance = [&]() {
+            if (req + 1 < total) {
+                ++req;
+                if (++pr == npair) { pr = 0; next_row(); }
             }
-            issue(pr, a_nxt, b_nxt);
+        };
+        setup_row();
 #pragma unroll
-            for (int j = 0; j < WG_RA; ++j)
+        for (int d = 0; d < WG_DEPTH; ++d) {
+            if (d) advance();
+            issue(pr, a_st[d], b_st[d]);
+        }
+        for (long long q = 0; q < total; q += WG_DEPTH) {
 #pragma unroll
-                for (int i = 0; i < WG_RB; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], b_cur[i], acc[j][i], 0, 0, 0);
+            for (int d = 0; d < WG_DEPTH; ++d) {
+                if (q + d < total) {
 #pragma unroll
-            for (int j = 0; j < WG_RA; ++j) a_cur[j] = a_nxt[j];
+                    for (int j = 0; j < WG_RA; ++j)
 #pragma unroll
-            for (int i = 0; i < WG_RB; ++i) b_cur[i] = b_nxt[i];
+                        for (int i = 0; i < WG_RB; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[d][j], b_st[d][i], acc[j][i], 0, 0, 0);
+                }
+                advance();
+                issue(pr, a_st[d], b_st[d]);             // step q + d + WG_DEPTH into the stage just consumed
+            }
         }
     }
     const int ldn = p.ncf * 32;
@@ -150,7 +182,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             if (cf >= p.ncf) continue;
             float* dst = p.part + (((long long)slab * p.nrf + rf) * 32) * ldn + cf * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2) + 4 * hh) * ldn] = acc[j][i][r];
+            for (int r = 0; r < 16; ++r) {
+                // (read out of the accumulator file element by element: left to itself the register allocator copies all 128
+                // accumulators into VGPRs at the loop exit -- 138 + 128 registers, one wave per SIMD instead of three)
+                float v;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[j][i][r]));
+                dst[(long long)((r & 3) + 8 * (r >> 2) + 4 * hh) * ldn] = v;
+            }
         }
     }
 }
@@ -176,7 +214,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+static int wgrad_ra(int nrf) { return nrf <= 2 ? 2 : 4; }        // accumulator tiles of a wave: RA x (8 / RA)
 static int wgrad_slabs(int nrf, int ncf, long long rows) {
+    const int WG_RA = wgrad_ra(nrf), WG_RB = 8 / WG_RA;
     const int units = ((nrf + WG_RA - 1) / WG_RA) * ((ncf + WG_RB - 1) / WG_RB), wgs = (units + 3) / 4;
     int nslab = std::max(1, (1024 + wgs - 1) / wgs);          // ~4 workgroups per CU
     const long long min_rows = 4;                             // at least a few rows per slab
@@ -814,6 +854,7 @@ int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, 
     p.fpr = (kw * C + 31) / 32;
     p.nrf = kf * kh * p.fpr;
     p.ncf = (N + 31) / 32;
+    const int WG_RA = wgrad_ra(p.nrf), WG_RB = 8 / WG_RA;
     p.nru = (p.nrf + WG_RA - 1) / WG_RA;
     p.ncu = (p.ncf + WG_RB - 1) / WG_RB;
     p.rows = (long long)B * F * Ho;
@@ -823,7 +864,9 @@ int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, 
     p.part = reinterpret_cast<float*>(align_up((size_t)ws, 256));
     {
         ProfScope prof(PROF_WGRAD, 2.0 * (double)p.rows * Wo * N * kf * kh * kw * C, 0, s);
-        hipLaunchKernelGGL(wgrad_kernel, dim3((p.nru * p.ncu + 3) / 4, p.nslab), dim3(256), 0, s, p);
+        const dim3 grid((p.nru * p.ncu + 3) / 4, p.nslab);
+        if (WG_RA == 2) hipLaunchKernelGGL((wgrad_kernel<2, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((wgrad_kernel<4, 2>), grid, dim3(256), 0, s, p);
         DPC_LAUNCH_CHECK();
     }
     ProfScope prof(PROF_TRAIN_MISC, 0, (double)p.nslab * tile_floats * 4, s);

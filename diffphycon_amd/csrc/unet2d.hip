@@ -26,6 +26,7 @@ struct dpc_unet2d_s {
     long long ws_key[3] = {0, 0, 0};      // (B, H, W) of the last workspace dry run and its result
     size_t ws_need = 0;
     dpc::Modes modes{2, 2, 2, 2};                                  // captured at create time (common.h: Modes)
+    bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 (captured at create) selects the unfused composition of LinearAttention (A/B tests)
     bool taps_on = false;
     struct Tap { std::unique_ptr<dpc::DevBuf> buf; size_t floats = 0; };
     std::map<std::string, Tap> taps;
@@ -204,6 +205,18 @@ struct Runner2D {
     void linear_attention(const std::string& p, float* x, int C, int Hl, int Wl) {
         const long long P = (long long)mb * Hl * Wl;
         const int HD = h->cfg.attn_heads * 32;
+        if (h->fused_attn && h->modes.attn == 2 && lattn3_supported(C, h->cfg.attn_heads) && h->raw.count(p + ".fn.fn.to_qkv.weight#h3")) {
+            // one launch per block, one workgroup per sample (lattn3.hip, OUT_LN form): x is read twice and written once, the
+            // qkv / attention / projection tensors never exist in HBM (shape-only rule: C = 64 / 128, 4 heads)
+            LattnParams lp{};
+            lp.x = x; lp.out = x; lp.gamma = raw(p + ".fn.norm.g"); lp.bout = raw(p + ".fn.fn.to_out.0.bias");
+            lp.gamma_out = raw(p + ".fn.fn.to_out.1.g");
+            lp.images = mb; lp.N = Hl * Wl;
+            const float* q3 = raw(p + ".fn.fn.to_qkv.weight#h3");
+            const float* o3 = raw(p + ".fn.fn.to_out.0.weight#h3");
+            RUN(launch_lattn3(lp, reinterpret_cast<const unsigned char*>(q3), reinterpret_cast<const unsigned char*>(o3), C, s));
+            return;
+        }
         const size_t m = ar.mark();
         float* stats = ar.allocf(P * 2);
         float* qkv = ar.allocf(P * 3 * HD);
@@ -376,6 +389,7 @@ int dpc_unet2d_create(const dpc_unet2d_cfg* cfg, dpc_unet2d_t* out) {
     auto* h = new dpc_unet2d_s();
     h->cfg = *cfg;
     h->modes = modes_global();
+    h->fused_attn = !debug_switch("DPC_UNFUSED_ATTN", 0);
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
     for (int i = 0; i < cfg->n_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);
@@ -422,6 +436,17 @@ int dpc_unet2d_load(dpc_unet2d_t h, const char* name_c, const float* w, const in
             rc = pack_conv3d(*pc, w, N, K, 1, kh, kw, 1, 1, 0, kh / 2, kw / 2, s);
         }
         h->conv[name] = std::move(pc);
+        // LinearAttention projections also as the pre-split per-head images of the weight-stationary fused kernel (lattn3.hip)
+        const bool is_qkv = ends_with2(name, ".fn.fn.to_qkv.weight"), is_out = ends_with2(name, ".fn.fn.to_out.0.weight");
+        if (!rc && (is_qkv || is_out) && kh == 1) {
+            const int C = is_out ? N : K, inner = is_out ? K : N / 3;
+            if (inner == 128 && lattn3_supported(C, h->cfg.attn_heads) && h->modes.attn == 2) {
+                auto b3 = std::make_unique<DevBuf>();
+                if ((rc = b3->alloc(is_out ? tattn3_out_bytes(C) : tattn3_qkv_bytes(C)))) return rc;
+                rc = launch_pack_tattn3(w, reinterpret_cast<unsigned char*>(b3->p), C, is_out, s);
+                h->raw[name + "#h3"] = std::move(b3);
+            }
+        }
     } else {
         auto b = std::make_unique<DevBuf>();
         if ((rc = b->alloc((size_t)numel * sizeof(float)))) return rc;

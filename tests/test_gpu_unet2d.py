@@ -66,6 +66,29 @@ def test_full_width_vs_oracle(mults, groups, B, dev):
     assert rel(y, ref) < 1e-4, rel(y, ref)
 
 
+def test_fused_linear_attention_equals_the_unfused_composition(dev, monkeypatch):
+    """r04: at C = 64 / 128 the LinearAttention block (PreNorm LayerNorm -> qkv -> softmaxes -> context -> to_out -> LayerNorm -> + x,
+    model/burgers_1d/unet.py:188-229) is ONE launch (lattn3.hip, OUT_LN form).  DPC_UNFUSED_ATTN=1 (captured when the handle is
+    created) keeps the composition of separate kernels: same arithmetic mode, different summation orders -> equal to rounding.
+    Measured 2.1e-6 (profiles/r04_tolerances.json); asserted at 3x that."""
+    from conftest import note_error
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from oracle import unet2d as U
+    mults = (1, 2, 4)
+    cfg = U.Unet2DConfig(dim=64, dim_mults=mults, resnet_block_groups=8)
+    sd = U.synthetic_state_dict(cfg, seed=9)
+    x = torch.randn(3, 2, 16, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+    t = torch.tensor([7, 400, 999]).to(dev)
+    outs = {}
+    for unfused in ("0", "1"):
+        monkeypatch.setenv("DPC_UNFUSED_ATTN", unfused)
+        m = Unet2D(dim=64, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=8)
+        m.load_state_dict(sd)
+        outs[unfused] = m.to(dev)(x, t)
+    assert not torch.equal(outs["0"], outs["1"]), "the switch did not select a different kernel"
+    assert note_error("unet2d fused vs unfused linear attention", rel(outs["0"], outs["1"])) < 7e-6
+
+
 def test_micro_batching_is_exact(dev):
     g = load_golden("unet2d_a")
     x = torch.randn(5, 2, 16, 32, generator=torch.Generator().manual_seed(0)).to(dev)
