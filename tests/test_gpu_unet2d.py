@@ -70,7 +70,7 @@ def test_fused_linear_attention_equals_the_unfused_composition(dev, monkeypatch)
     """r04: at C = 64 / 128 the LinearAttention block (PreNorm LayerNorm -> qkv -> softmaxes -> context -> to_out -> LayerNorm -> + x,
     model/burgers_1d/unet.py:188-229) is ONE launch (lattn3.hip, OUT_LN form).  DPC_UNFUSED_ATTN=1 (captured when the handle is
     created) keeps the composition of separate kernels: same arithmetic mode, different summation orders -> equal to rounding.
-    Measured 2.1e-6 (profiles/r04_tolerances.json); asserted at 3x that."""
+    Measured 5.1e-7 of the output range (profiles/r04_l_tol.jsonl); asserted at 3x that."""
     from conftest import note_error
     from diffphycon_amd.model.burgers_1d.unet import Unet2D
     from oracle import unet2d as U
@@ -86,7 +86,7 @@ def test_fused_linear_attention_equals_the_unfused_composition(dev, monkeypatch)
         m.load_state_dict(sd)
         outs[unfused] = m.to(dev)(x, t)
     assert not torch.equal(outs["0"], outs["1"]), "the switch did not select a different kernel"
-    assert note_error("unet2d fused vs unfused linear attention", rel(outs["0"], outs["1"])) < 7e-6
+    assert note_error("unet2d fused vs unfused linear attention", rel(outs["0"], outs["1"])) < 1.6e-6
 
 
 def test_micro_batching_is_exact(dev):
