@@ -439,8 +439,10 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
     sd_cpu = {k: v.clone() for k, v in m.state_dict().items()}
     gd = GaussianDiffusion(m, image_size=SIZE, frames=FRAMES, timesteps=1000, sampling_timesteps=250, loss_type="l2",
                            objective="pred_noise", device=ctx.device)
-    bwd_mode = os.environ.get("DPC_TRAIN_BWD_MODE", "x6")
-    loss_scale = float(os.environ.get("DPC_TRAIN_LOSS_SCALE", "1"))
+    # the Trainer's defaults (r04): backward-data convolutions f16x3 under the dynamic loss scale; DPC_TRAIN_BWD_MODE=x6 times the exact mode alone
+    bwd_mode = os.environ.get("DPC_TRAIN_BWD_MODE", "f16x3")
+    ls_env = os.environ.get("DPC_TRAIN_LOSS_SCALE", "dynamic" if bwd_mode == "f16x3" else "1")
+    loss_scale = ls_env if ls_env == "dynamic" else float(ls_env)
     tr = Trainer(gd, "Smoke", None, train_batch_size=batch * ctx.world, train_lr=1e-3, is_w_model=False, bwd_mode=bwd_mode,
                  loss_scale=loss_scale)
     g = torch.Generator().manual_seed(100 + ctx.rank)
@@ -452,14 +454,16 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
     sec, sec_min, prof_all, prof, warm_ms = timed_loop(ctx, step, args.steps, max(args.warmup, 1))
     first, last = float(losses[0].item()), float(losses[-1].item())
     assert torch.isfinite(tr._t.w).all() and last == last, "non-finite weights / loss after the timed steps"
+    tr.check_gradient_range()                 # (raises if an operand of the f16x3 kernels left its window during the timed steps)
     out = {"metric": "training samples/sec, 2D smoke 64x64x32 joint denoiser (p_losses forward + backward + clip + Adam + EMA)",
            "value": ctx.world * batch / sec, "unit": "samples/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": sec * 1e3, "ms_per_step_min_rank": sec_min * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": dtype_label(getattr(gd.model, "modes", "")), "data": "synthetic",
            "world_size_seen_by_rccl": ctx.seen_world,
            "arithmetic": f"forward {gd.model.modes if hasattr(gd.model, 'modes') else ''}; backward-data convolutions {bwd_mode}"
-                         f" (loss scale {loss_scale:g}); weight gradients: 3x3x3 convolutions f16x3 (wgrad3.hip), every other geometry "
-                         "exact fp32 products on the native fp32 MFMA",
+                         f" (loss scale {loss_scale if isinstance(loss_scale, str) else format(loss_scale, 'g')}: 2^{int(__import__('math').log2(tr.loss_scale))} "
+                         f"after the timed steps, {tr.skipped_steps} skipped); weight gradients: 3x3x3 convolutions f16x3 (wgrad3.hip), every "
+                         "other geometry exact fp32 products on the native fp32 MFMA",
            "loss_first_last": [first, last],
            "config": {"workload": "S64 training step (SURVEY 8 f-4; scripts/smoke_train_joint.sh): Unet3D(dim 64, mults 1-2-4, 6 "
                                   f"channels) on 64x64 x 32 frames, batch={batch} per GPU, one optimizer step per bench step",
@@ -467,6 +471,22 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
     if ctx.rank == 0:
         out["roofline"] = roofline_of(prof, prof_all, "", sec, args.steps, warm_ms, 3 * batch * TRAIN_FWD_GFLOP / 1e3)
     ctx.log(t_start, f"train: {sec * 1e3:.1f} ms per optimizer step, loss {first:.4f} -> {last:.4f}")
+    if bwd_mode == "f16x3":
+        # the same step with EXACT backward-data products (bf16x6, loss scale 1: Trainer(bwd_mode="x6"), train_2d_smoke.py --bwd_mode x6;
+        # DESIGN.md 8), as `value_exact` does for the sampling loop: reported beside the default, never as `value`
+        del tr
+        torch.cuda.empty_cache()
+        tr6 = Trainer(gd, "Smoke", None, train_batch_size=batch * ctx.world, train_lr=1e-3, is_w_model=False, bwd_mode="x6")
+        l6 = []
+        sec6, sec6_min, _, _, _ = timed_loop(ctx, lambda: l6.append(tr6.train_step([state])), args.steps, max(args.warmup, 1), profile=False)
+        f6, b6 = float(l6[0].item()), float(l6[-1].item())
+        assert torch.isfinite(tr6._t.w).all() and b6 == b6, "non-finite weights / loss in the exact-backward leg"
+        tr6.check_gradient_range()
+        out["exact_backward"] = {"ms_per_step": sec6 * 1e3, "ms_per_step_min_rank": sec6_min * 1e3, "value": ctx.world * batch / sec6,
+                                 "unit": "samples/s", "loss_first_last": [f6, b6],
+                                 "note": "backward-data convolutions with exact fp32 products (bf16x6, direct 3x3x3 kernel), loss scale 1"}
+        ctx.log(t_start, f"train (exact backward, x6): {sec6 * 1e3:.1f} ms per optimizer step")
+        del tr6
     out["cpu_baseline"] = None
     if with_cpu and ctx.rank == 0 and ctx.world == 1:
         from oracle import train_smoke as TS

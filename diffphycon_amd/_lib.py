@@ -95,6 +95,7 @@ _SIGNATURES = {
     "dpc_unet3d_set_range_check": (C.c_int, [_P, _I]),
     "dpc_unet3d_range_status": (C.c_int, [_P, _I, _P]),
     "dpc_train_range_status": (C.c_int, [_I, _P]),
+    "dpc_train_range_poison": (C.c_int, [_P, _P]),
     "dpc_selftest_fp16_clamp": (C.c_int, [_P, _P, _I, _P]),
     "dpc_profile_begin": (C.c_int, []),
     "dpc_profile_begin_classes": (C.c_int, [C.c_char_p]),
@@ -153,7 +154,7 @@ _SIGNATURES = {
     "dpc_stem_free": (None, [_P]),
     "dpc_stem_run": (C.c_int, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "dpc_conv_wgrad_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _L]),
-    "dpc_conv_wgrad_cl": (C.c_int, [_P, _P, _P] + [_I] * 19 + [C.c_float, C.c_float, _I, _P, _Z, _P]),
+    "dpc_conv_wgrad_cl": (C.c_int, [_P, _P, _P] + [_I] * 19 + [C.c_float, C.c_float, C.c_float, _I, _P, _Z, _P]),
     "dpc_colsum_workspace_bytes": (_Z, [_I]),
     "dpc_colsum": (C.c_int, [_P, _P, _P, _P, _L, _I, C.c_float, _I, _P, _Z, _P]),
     "dpc_gn_silu_bwd_params": (C.c_int, [_P] * 10 + [_I, _L, _I, _I, _P, _Z, _P]),

@@ -259,6 +259,7 @@ int f16x3_weight_overflow_check(const char* who);   // DPC_OK, or DPC_ERR_STATE 
 // is clamped); dpc_train_range_status reads it (one host sync; the Trainer asks when it logs the loss, never per step)
 int* f16x3_grad_overflow_flag();
 int f16x3_grad_overflow_status(int reset, hipStream_t s);
+int f16x3_grad_overflow_poison(float* g, hipStream_t s);
 int igemm_npad(int N);
 int igemm_kchunks(int K);
 int launch_igemm(const IgemmParams& p, hipStream_t s);

@@ -44,6 +44,9 @@ struct WgradParams {
     int kf, kh, kw, sh, sw, pf, ph, pw;
     int fpr, nrf, ncf, nru, ncu, nslab;
     long long rows;            // B * F * Ho
+    unsigned dy_limit_bits;    // != 0: an operand element with |v| above this (bit pattern of a positive float; Inf / NaN too) raises
+    int* oflag;                //       bit 1 of the gradient-range sentinel (wgrad3.hip) -- the gradient operand is also the input of
+                               //       this layer's f16x3 backward-DATA convolution, which clamps there
 };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -138,6 +141,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             b[i] = bload(rb, eb[i] + (unsigned)pr * bstep);
         }
     };
+    unsigned bmax = 0;                       // largest |operand| bit pattern this lane multiplied (both sides: a ConvTranspose passes its
+                                             // output gradient as x, include/dpc.h)
     if (row_begin < row_end) {
         // request cursor (row, pr) of step `req`; it runs WG_DEPTH steps ahead of the multiplications and stops at the last step
         // (steps past the end re-request the last one: harmless, never multiplied)
@@ -165,12 +170,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
                         for (int i = 0; i < WG_RB; ++i)
                             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_st[d][j], b_st[d][i], acc[j][i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < WG_RB; ++i) bmax = max(bmax, __builtin_bit_cast(unsigned, b_st[d][i]) & 0x7fffffffu);
+#pragma unroll
+                    for (int j = 0; j < WG_RA; ++j) bmax = max(bmax, __builtin_bit_cast(unsigned, a_st[d][j]) & 0x7fffffffu);
                 }
                 advance();
                 issue(pr, a_st[d], b_st[d]);             // step q + d + WG_DEPTH into the stage just consumed
             }
         }
     }
+    if (p.dy_limit_bits && bmax > p.dy_limit_bits) atomicOr(p.oflag, 2);
     const int ldn = p.ncf * 32;
 #pragma unroll
     for (int j = 0; j < WG_RA; ++j) {
@@ -214,9 +224,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-static int wgrad_ra(int nrf) { return nrf <= 2 ? 2 : 4; }        // accumulator tiles of a wave: RA x (8 / RA)
+// accumulator tiles of a wave: 2 x 4 when the row operand has two fragments, else 4 x 2 (three waves per SIMD).  A 4 x 4 form (256
+// accumulators, one wave per SIMD, twice the FLOP per loaded byte) was measured and lost: 265.9 vs 263.5 ms per training step (r04_m)
+static void wgrad_shape(int nrf, int ncf, int& ra, int& rb) {
+    (void)ncf;
+    if (nrf <= 2) { ra = 2; rb = 4; }
+    else { ra = 4; rb = 2; }
+}
 static int wgrad_slabs(int nrf, int ncf, long long rows) {
-    const int WG_RA = wgrad_ra(nrf), WG_RB = 8 / WG_RA;
+    int WG_RA, WG_RB;
+    wgrad_shape(nrf, ncf, WG_RA, WG_RB);
     const int units = ((nrf + WG_RA - 1) / WG_RA) * ((ncf + WG_RB - 1) / WG_RB), wgs = (units + 3) / 4;
     int nslab = std::max(1, (1024 + wgs - 1) / wgs);          // ~4 workgroups per CU
     const long long min_rows = 4;                             // at least a few rows per slab
@@ -819,6 +836,7 @@ using namespace dpc;
 extern "C" {
 
 int dpc_train_range_status(int reset, dpc_stream_t stream) { return f16x3_grad_overflow_status(reset, (hipStream_t)stream); }
+int dpc_train_range_poison(float* g, dpc_stream_t stream) { return f16x3_grad_overflow_poison(g, (hipStream_t)stream); }
 
 size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows) {
     const int fpr = (kw * C + 31) / 32;
@@ -830,8 +848,9 @@ size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int6
 
 int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, int Hi, int Wi, int C, int Ho, int Wo, int N, int kf,
                       int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
-                      float f16_dy_scale, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream) {
+                      float f16_dy_scale, float dy_abs_limit, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream) {
     DPC_REQUIRE(x && dy && dw && ws, "conv_wgrad: null argument");
+    DPC_REQUIRE(dy_abs_limit >= 0.f, "conv_wgrad: dy_abs_limit must be >= 0 (0 = no check)");
     DPC_REQUIRE(B >= 1 && F >= 1 && C >= 1 && N >= 1 && kf >= 1 && kh >= 1 && kw >= 1 && sh >= 1 && sw >= 1, "conv_wgrad: bad shape");
     DPC_REQUIRE(C % 32 == 0 || 32 % C == 0, "conv_wgrad: input channels must divide or be a multiple of 32 (pad on the host)");
     DPC_REQUIRE((long long)Wi * C * 4 < (1ll << 31) && (long long)Wo * N * 4 < (1ll << 31), "conv_wgrad: row too long");
@@ -854,10 +873,14 @@ int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, 
     p.fpr = (kw * C + 31) / 32;
     p.nrf = kf * kh * p.fpr;
     p.ncf = (N + 31) / 32;
-    const int WG_RA = wgrad_ra(p.nrf), WG_RB = 8 / WG_RA;
+    int WG_RA, WG_RB;
+    wgrad_shape(p.nrf, p.ncf, WG_RA, WG_RB);
     p.nru = (p.nrf + WG_RA - 1) / WG_RA;
     p.ncu = (p.ncf + WG_RB - 1) / WG_RB;
     p.rows = (long long)B * F * Ho;
+    p.dy_limit_bits = dy_abs_limit > 0.f ? __builtin_bit_cast(unsigned, dy_abs_limit) : 0u;
+    p.oflag = p.dy_limit_bits ? f16x3_grad_overflow_flag() : nullptr;
+    DPC_REQUIRE(!p.dy_limit_bits || p.oflag, "conv_wgrad: cannot allocate the gradient-range sentinel word");
     p.nslab = wgrad_slabs(p.nrf, p.ncf, p.rows);
     const size_t tile_floats = (size_t)p.nrf * 32 * p.ncf * 32;
     DPC_REQUIRE(ws_bytes >= (size_t)p.nslab * tile_floats * sizeof(float) + 256, "conv_wgrad: workspace too small");

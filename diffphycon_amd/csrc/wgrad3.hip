@@ -323,6 +323,24 @@ int f16x3_grad_overflow_status(int reset, hipStream_t s) {
                                "lower the loss scale or use wgrad_mode='f32'");
 }
 
+// Dynamic loss scaling without a per-step flag read or an extra collective: if an output gradient left the fp16 window since the last
+// call (bit 1), the first element of the flat gradient buffer becomes +inf -- the all-reduce that follows spreads it to every rank, the
+// gradient norm every rank computes anyway is then not finite, and all ranks skip the step together.  Clears bit 1.
+__global__ void grad_poison_kernel(int* flag, float* g) {
+    const int v = *flag;
+    if (v & 2) {
+        g[0] = INFINITY;
+        *flag = v & ~2;
+    }
+}
+int f16x3_grad_overflow_poison(float* g, hipStream_t s) {
+    int* flag = f16x3_grad_overflow_flag();
+    DPC_REQUIRE(flag && g, "train_range_poison: null argument");
+    hipLaunchKernelGGL(grad_poison_kernel, dim3(1), dim3(1), 0, s, flag, g);
+    DPC_LAUNCH_CHECK();
+    return DPC_OK;
+}
+
 int launch_wgrad3(const float* x, const float* dy, float* dw, int B, int F, int H, int W, int C, int N, int ctot, int coff, float x_scale,
                   float dy_scale, float out_scale, int accumulate, void* ws, hipStream_t s) {
     Wgrad3Params p{};

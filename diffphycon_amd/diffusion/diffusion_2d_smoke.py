@@ -407,7 +407,7 @@ class Trainer(object):
     def __init__(self, diffusion_model, dataset=None, dataset_path=None, *, train_batch_size=16, gradient_accumulate_every=1,
                  train_lr=1e-4, train_num_steps=100000, ema_update_every=10, ema_decay=0.995, adam_betas=(0.9, 0.99),
                  save_and_sample_every=1000, num_samples=25, results_path="./results", amp=False, fp16=False, split_batches=True,
-                 is_schedule=True, resume=False, resume_step=0, is_w_model=True, bwd_mode="x6", loss_scale=1.0, data=None,
+                 is_schedule=True, resume=False, resume_step=0, is_w_model=True, bwd_mode="f16x3", loss_scale=None, data=None,
                  max_grad_norm=1.0, **unused):
         from pathlib import Path
         self.model = diffusion_model
@@ -422,7 +422,18 @@ class Trainer(object):
         self.save_and_sample_every = save_and_sample_every
         self.is_schedule, self.is_w_model = is_schedule, is_w_model
         self.max_grad_norm = max_grad_norm
-        self.bwd_mode, self.loss_scale = bwd_mode, loss_scale
+        # backward-data arithmetic: "f16x3" (default since r04) = the forward's 22-bit split operands, which needs the
+        # gradients scaled into the fp16 window: loss_scale="dynamic" (its default) = what accelerate's GradScaler does for the
+        # reference's Trainer(fp16=True) (:871-874): start at 2^20, skip the step and halve when a gradient overflowed (every layer's
+        # weight-gradient launch watches its gradient operand: include/dpc.h), double after 2000 clean steps; or a fixed power of two.
+        # "x6" / "f32" = exact fp32 products, loss scale 1 (`exact_backward` in bench.py).
+        if loss_scale is None:
+            loss_scale = "dynamic" if bwd_mode == "f16x3" else 1.0
+        self.dynamic_scale = isinstance(loss_scale, str)
+        if self.dynamic_scale and loss_scale != "dynamic":
+            raise ValueError("loss_scale: a power of two or 'dynamic'")
+        self.bwd_mode, self.loss_scale = bwd_mode, (2.0 ** 20 if self.dynamic_scale else float(loss_scale))
+        self.scale_growth_interval, self.good_steps, self.skipped_steps = 2000, 0, 0
         self.ema_sched = _EmaSchedule(beta=ema_decay, update_every=ema_update_every)
         self._data = data
         self._t = None                  # TrainableUnet3D, built on first use (the checkpoint reader needs none of this)
@@ -455,6 +466,14 @@ class Trainer(object):
         if opt is not None and not (isinstance(opt, dict) and "state" in opt and "param_groups" in opt):
             raise ValueError(f"{path}: 'opt' is not a torch.optim.Adam state_dict (keys {sorted(opt) if isinstance(opt, dict) else type(opt)})")
         self._pending = (opt, ema)
+        sc = data.get("scaler")
+        if self.dynamic_scale and isinstance(sc, dict) and sc.get("scale"):
+            import math
+            scale = float(sc["scale"])
+            if math.frexp(scale)[0] == 0.5 and 1.0 <= scale <= 2.0 ** 24:          # (a GradScaler scale is a power of two as well)
+                self.loss_scale, self.good_steps = scale, int(sc.get("_growth_tracker", 0))
+                if self._t is not None:
+                    self._t.set_loss_scale(scale)
         if self._t is not None:
             self._after_weight_change(reload=True)
             self._apply_pending()
@@ -508,7 +527,10 @@ class Trainer(object):
             ema.update({"online_model." + k: t.detach().cpu().clone() for k, t in online.items()})
             ema.update({"ema_model." + k: t.detach().cpu().clone() for k, t in online.items()})      # buffers: equal on both copies
             ema.update({"ema_model.model." + k: t for k, t in views(self.ema).items()})
-        data = {"step": self.step, "model": self.model.state_dict(), "opt": opt, "ema": ema, "scaler": None}
+        # torch.cuda.amp.GradScaler.state_dict()'s layout (what accelerate stores for Trainer(fp16=True), :951)
+        scaler = {"scale": float(self.loss_scale), "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": self.scale_growth_interval,
+                  "_growth_tracker": int(self.good_steps % self.scale_growth_interval)} if self.dynamic_scale else None
+        data = {"step": self.step, "model": self.model.state_dict(), "opt": opt, "ema": ema, "scaler": scaler}
         torch.save(data, str(self.results_path / f"model-{milestone}.pt"))
 
     # ------------------------------------------------------------------ training state
@@ -564,10 +586,26 @@ class Trainer(object):
         from ..parallel import allreduce_sum_
         T, L = self._t, _lib.lib()
         g = T.g if self._acc is None else self._acc
+        if self.dynamic_scale:                 # an overflowed gradient on ANY rank makes every rank's norm non-finite (include/dpc.h)
+            _lib.check(L.dpc_train_range_poison(_lib.ptr(g), _lib.stream()))
         world = allreduce_sum_(g)
         ginv = 1.0 / (T.loss_scale * world * (self.gradient_accumulate_every if self._acc is not None else 1))
         p, n = T.ctx.ws(L.dpc_reduce_workspace_bytes())
         _lib.check(L.dpc_l2_norm(_lib.ptr(g), g.numel(), ginv, _lib.ptr(self.norm), p, n, _lib.stream()))
+        if self.dynamic_scale:
+            import math
+            if not math.isfinite(float(self.norm.item())):          # the ONE host read of a step in this mode
+                self.skipped_steps += 1
+                self.good_steps = 0
+                if T.loss_scale <= 1.0:
+                    raise FloatingPointError("dynamic loss scale: gradients are not finite at loss scale 1")
+                T.set_loss_scale(T.loss_scale / 2)
+                self.loss_scale = T.loss_scale
+                return False                                         # weights, moments, EMA and both schedules stay where they were
+            self.good_steps += 1
+            if self.good_steps % self.scale_growth_interval == 0 and T.loss_scale < 2.0 ** 24:
+                T.set_loss_scale(T.loss_scale * 2)
+                self.loss_scale = T.loss_scale
         mode, wgt = self.ema_sched.next()
         lr = self._lr()
         self.opt_step += 1
@@ -575,6 +613,7 @@ class Trainer(object):
                                        _lib.ptr(self.norm), float(self.max_grad_norm or 0.0), ginv, lr, self.adam_betas[0],
                                        self.adam_betas[1], 1e-8, self.opt_step, mode, wgt, _lib.stream()))
         self._after_weight_change()
+        return True
 
     def check_gradient_range(self):
         """The f16x3 weight-gradient sentinel (include/dpc.h: dpc_train_range_status): raises when an operand of a weight-gradient
@@ -629,7 +668,8 @@ class Trainer(object):
                 self.losses.append((self.step, float(loss.item())))
                 self.check_gradient_range()
                 if parallel.rank() == 0:
-                    print(f"step: {self.step}, loss: {self.losses[-1][1]:.4f}, LR: {self._lr()}", flush=True)
+                    extra = f", loss scale: 2^{int(round(__import__('math').log2(self.loss_scale)))}, skipped: {self.skipped_steps}" if self.dynamic_scale else ""
+                    print(f"step: {self.step}, loss: {self.losses[-1][1]:.4f}, LR: {self._lr()}{extra}", flush=True)
             if self.step % self.save_and_sample_every == 0:
                 self.check_gradient_range()          # never checkpoint weights that came from clamped gradients
                 if parallel.rank() == 0:

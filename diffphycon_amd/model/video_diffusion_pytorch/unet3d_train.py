@@ -63,6 +63,9 @@ class _Ctx:
         self._ws = None
         self.act_scale = 0.0           # operand scale of the f16x3 backward-data convolutions (0: the library default 2^4)
         self.wgrad_dy_scale = 0.0      # != 0: 3x3x3 weight gradients on the fp16 matrix cores, dy pre-scaled by this power of two
+        # f16x3 backward-data convolutions clamp |scaled gradient| > 65504 / 2^4: every layer's weight-gradient launch watches the
+        # same tensor and raises the sentinel (include/dpc.h: dpc_conv_wgrad_cl dy_abs_limit) -- no clamp goes unseen
+        self.dgrad_limit = 4094.0 if bwd_mode == "f16x3" else 0.0
 
     def ws(self, nbytes):
         nbytes = int(nbytes) + 512
@@ -145,7 +148,7 @@ class _Ctx:
         L = _lib.lib()
         p, n = self.ws(L.dpc_conv_wgrad_workspace_bytes(Cc, N, kd, kh, kw, B * F * Ho))
         _lib.check(L.dpc_conv_wgrad_cl(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, F, Hi, Wi, Cc, Ho, Wo, N, kd, kh, kw, sh, sw, pd, ph, pw,
-                                       c_valid, ctot, coff, 1.0, self.wgrad_dy_scale, 0, p, n, _lib.stream()))
+                                       c_valid, ctot, coff, 1.0, self.wgrad_dy_scale, self.dgrad_limit, 0, p, n, _lib.stream()))
 
 
 class _Pack:
@@ -495,16 +498,11 @@ class TrainableUnet3D:
         self.module, self.device = module, device
         m = module
         self.dim, self.mults, self.channels, self.out_dim = m.dim, tuple(m.dim_mults), m.channels, m.out_dim
-        self.loss_scale = float(loss_scale)
-        assert math.frexp(self.loss_scale)[0] == 0.5, "loss_scale must be a power of two"
         self.ctx = ctx = _Ctx(device, m.resnet_groups, m.attn_heads, fwd_mode, bwd_mode)
         if wgrad_mode not in ("f16x3", "f32"):
             raise ValueError("wgrad_mode: 'f16x3' (3x3x3 weight gradients on the fp16 matrix cores) | 'f32' (native fp32 MFMA)")
-        # the gradient operand of the f16x3 weight-gradient kernel is scaled so that d loss / d eps * 2^24 is what gets split:
-        # d eps ~ 2 (eps - noise) / numel ~ 1e-7 lands at O(1), as it does for the f16x3 backward-data convolutions (loss scale
-        # 2^20 times the operand pre-scale 2^4)
-        ctx.wgrad_dy_scale = (2.0 ** 24) / self.loss_scale if wgrad_mode == "f16x3" else 0.0
         self.wgrad_mode = wgrad_mode
+        self.set_loss_scale(loss_scale)
         # ---- flat parameter / gradient buffers; module parameters become views
         self.names = list(m._names)
         params = dict(m.named_parameters())
@@ -557,6 +555,18 @@ class TrainableUnet3D:
         self.opad = (self.out_dim + 3) // 4 * 4
 
     # ------------------------------------------------------------------ packing
+
+    def set_loss_scale(self, loss_scale):
+        """Power-of-two factor on d loss / d eps (undone inside the optimizer kernel).  It may change between steps (the Trainer's
+        dynamic scaling): nothing on the device depends on it except the two scalars below."""
+        self.loss_scale = float(loss_scale)
+        assert self.loss_scale > 0 and math.frexp(self.loss_scale)[0] == 0.5, "loss_scale must be a power of two"
+        # the gradient operand of the f16x3 weight-gradient kernel is scaled so that d loss / d eps * 2^24 is what gets split:
+        # d eps ~ 2 (eps - noise) / numel ~ 1e-7 lands at O(1), as it does for the f16x3 backward-data convolutions (loss scale
+        # 2^20 times the operand pre-scale 2^4)
+        # (above 2^20 the operand scale stays 2^4, the forward's: the window |scaled gradient| <= 4094 is then the backward-data
+        #  convolutions' as well, and halving the loss scale widens both)
+        self.ctx.wgrad_dy_scale = max(16.0, (2.0 ** 24) / self.loss_scale) if self.wgrad_mode == "f16x3" else 0.0
     def _blocks(self):
         yield self.init_attn
         for lv in self.downs + self.ups:

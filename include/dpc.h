@@ -319,15 +319,26 @@ int dpc_stem_run(dpc_stem_t h, const float* x, int x_channels_total, int x_chann
  * run on the fp16 matrix cores instead (csrc/wgrad3.hip: LDS transpose reads, f16x3 = 22-bit split operands, 3 MFMAs per product,
  * fp32 accumulation): x is pre-scaled by 2^4 like every f16x3 activation operand, dy by f16_dy_scale (saturating at 65504), both
  * undone in the fixed-order reduction; other shapes ignore the flag.  rows of the workspace query: B * F * Ho.
+ * dy_abs_limit > 0 (r04; the launches that stay on the fp32 MFMA): an element of either operand with |v| > dy_abs_limit (or not
+ * finite) raises bit 1 of the same device word -- the gradient operand of a layer's weight gradient is the input of that layer's
+ * backward-DATA convolution, which CLAMPS at 4094 in the f16x3 mode: with dy_abs_limit = 4094 on every layer no backward-data clamp
+ * goes unseen (the f16x3 launches check theirs against 65504 / f16_dy_scale <= 4094).  0 = no check.
  * Both operands SATURATE at the fp16 limit (|x| > 4094, |dy| > 65504 / f16_dy_scale) and a saturated (or non-finite) element raises
  * a device word; dpc_train_range_status reads it (ONE host sync; reset != 0 clears it): DPC_OK, or DPC_ERR_STATE when any
  * f16x3 weight-gradient launch since the last reset clamped an operand -- that step's gradients are then not exact.  The Trainer
  * (diffusion_2d_smoke.py Trainer.train :998-1054) asks where it already syncs: when it logs the loss and before it saves. */
 int dpc_train_range_status(int reset, dpc_stream_t stream);
+/* Dynamic loss scaling (what accelerate's GradScaler does for Trainer(fp16=True), diffusion_2d_smoke.py:871-874, 1025-1035: skip the
+ * step and halve the scale when a gradient overflowed): enqueue BEFORE the gradient all-reduce.  If an output gradient was clamped /
+ * not finite since the last call (bit 1 of the word above) g[0] (the flat gradient buffer) becomes +inf and the bit is cleared: the
+ * all-reduce carries it to every rank, dpc_l2_norm's result is then not finite on all of them, and the host -- which reads that norm
+ * once per step in this mode -- skips dpc_adam_ema_step everywhere.  No host sync, no extra collective.  Bit 0 (an ACTIVATION
+ * outside |x| <= 4094: not a loss-scale matter) stays for dpc_train_range_status. */
+int dpc_train_range_poison(float* g, dpc_stream_t stream);
 size_t dpc_conv_wgrad_workspace_bytes(int C, int N, int kf, int kh, int kw, int64_t rows /* B * F * Ho */);
 int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, int Hi, int Wi, int C, int Ho, int Wo, int N, int kf,
                       int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
-                      float f16_dy_scale, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream);
+                      float f16_dy_scale, float dy_abs_limit, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream);
 /* out[c] = (accumulate ? out[c] : 0) + scale * sum_r dy[r][c] (x NULL: bias gradients) or
  * scale * sum_r dy[r][c] (x[r][c] - mean_r) rstd_r (channel-LayerNorm gamma gradient :195-204, ln_stats [rows][2]); fp64 partials */
 size_t dpc_colsum_workspace_bytes(int C);

@@ -47,17 +47,40 @@ def _check_grads(T, g, step, tol, scale=1.0):
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize("bwd_mode", ["x6", "f32"])
+@pytest.mark.parametrize("bwd_mode,loss_scale", [("x6", 1.0), ("f32", 1.0), ("f16x3", 2.0 ** 12)])
 @pytest.mark.parametrize("tag", ["joint", "w", "wide"])
-def test_loss_and_every_gradient_match_the_reference(tag, bwd_mode, dev):
+def test_loss_and_every_gradient_match_the_reference(tag, bwd_mode, loss_scale, dev):
+    """(r04) 'f16x3' = backward-data convolutions on 22-bit split operands under a power-of-two loss scale: same records, same
+    tolerance.  (The fixture nets are tiny -- d loss / d eps = 2 (eps - noise) / numel is ~1e-3 per element, 1e4 times the S64
+    net's -- so the scale that suits them is 2^12, not S64's 2^20, which the sentinel rejects: next test.)"""
     g = load_golden(f"train_{tag}")
-    T = _net(g, dev, bwd_mode)
+    T = _net(g, dev, bwd_mode, loss_scale=loss_scale)
     a, b = _sched(dev)
     coff = 3 if int(g["channels"]) == 2 else 0
     x0 = torch.from_numpy(g["s0:state"]).to(dev)
     loss = T.p_losses(x0, torch.from_numpy(g["s0:t"]).to(dev), torch.from_numpy(g["s0:noise"]).to(dev), a, b, channel_offset=coff)
     assert abs(loss.item() - float(g["s0:loss"])) < 1e-5 * float(g["s0:loss"])
-    _check_grads(T, g, 0, 1e-4)
+    _check_grads(T, g, 0, 1e-4, scale=loss_scale)
+    _lib_status = __import__("diffphycon_amd._lib", fromlist=["x"])
+    assert _lib_status.lib().dpc_train_range_status(1, _lib_status.stream()) == 0        # nothing was clamped on the way
+
+
+@pytest.mark.parametrize("tag", ["w"])
+def test_a_loss_scale_the_gradients_cannot_take_raises_the_sentinel(tag, dev):
+    """r04: 2^20 on the tiny prior-net fixture scales its output gradients past 4094, where the f16x3 backward-data convolutions
+    clamp -- silently before r04 (gradients off by 5 %).  Every layer's weight-gradient launch now watches its gradient operand
+    (dpc_conv_wgrad_cl: dy_abs_limit), so the step is reported: dpc_train_range_status != 0, Trainer.check_gradient_range raises,
+    and the dynamic scaler (next test) skips it."""
+    from diffphycon_amd import _lib as L
+    g = load_golden(f"train_{tag}")
+    T = _net(g, dev, "f16x3", loss_scale=2.0 ** 20)
+    a, b = _sched(dev)
+    coff = 3 if int(g["channels"]) == 2 else 0
+    L.lib().dpc_train_range_status(1, L.stream())
+    T.p_losses(torch.from_numpy(g["s0:state"]).to(dev), torch.from_numpy(g["s0:t"]).to(dev), torch.from_numpy(g["s0:noise"]).to(dev), a, b,
+               channel_offset=coff)
+    assert L.lib().dpc_train_range_status(1, L.stream()) != 0
+    assert "output gradient" in L.lib().dpc_last_error().decode()
 
 
 def _trainer(g, dev, bwd_mode="x6", **kw):
@@ -95,6 +118,70 @@ def test_optimizer_steps_match_the_reference(tag, dev):
             live = torch.from_numpy(np.abs(g[f"s0:g:{k}"]) > 1e-4 * G)
             assert d[live].numel() == 0 or d[live].max().item() < 3e-2 * lr, (step, k, d[live].max().item())
             assert d.max().item() < 2.1 * lr * (step + 1), (step, k)
+
+
+def test_dynamic_loss_scale_matches_the_reference_steps_and_skips_on_overflow(dev):
+    """r04: Trainer(bwd_mode="f16x3", loss_scale="dynamic") -- backward-data convolutions on the forward's 22-bit split operands, the
+    gradients scaled by a power of two that follows accelerate's GradScaler rule (the reference's Trainer(fp16=True), :871-874): the
+    two recorded steps match the reference like the exact mode does; an overflowing output gradient (forced here by a loss scale the
+    gradients cannot take) skips the step on the device-resident norm, halves the scale and leaves weights / moments / EMA / step
+    counters untouched."""
+    g = load_golden("train_joint")
+    tr = _trainer(g, dev, bwd_mode="f16x3", loss_scale="dynamic")
+    lr = float(g["lr"])
+    assert tr.loss_scale == 2.0 ** 20
+    w0 = None
+    for step in range(2):
+        for attempt in range(16):            # (a tiny net's gradients can be 1e4 x S64's: the scaler may walk down from 2^20 first)
+            loss = tr.loss_and_gradients(torch.from_numpy(g[f"s{step}:state"]).to(dev), torch.from_numpy(g[f"s{step}:t"]).to(dev),
+                                         torch.from_numpy(g[f"s{step}:noise"]).to(dev))
+            assert abs(loss.item() - float(g[f"s{step}:loss"])) < 2e-5 * float(g[f"s{step}:loss"])
+            if w0 is None:
+                w0 = tr._t.w.clone()
+            if tr.optimizer_step():
+                break
+            assert step == 0 and torch.equal(tr._t.w, w0) and tr.opt_step == 0          # a skipped step changes nothing
+        _check_grads(tr._t, g, step, 2e-4 if step else 1e-4, scale=tr._t.loss_scale)
+        assert abs(tr.norm.item() - float(g[f"s{step}:grad_norm"])) < 1e-4 * float(g[f"s{step}:grad_norm"])
+    assert 2.0 ** 8 <= tr.loss_scale <= 2.0 ** 20 and tr.opt_step == 2
+    print(f"dynamic loss scale settled at 2^{int(np.log2(tr.loss_scale))} after {tr.skipped_steps} skipped steps")
+    G = max(float(np.abs(g[f"s0:g:{k}"]).max()) for k in tr._t.names)
+    sd = tr.model.model.state_dict()
+    for k in tr._t.names:
+        d = (sd[k].cpu() - torch.from_numpy(g[f"s1:w:{k}"])).abs()
+        live = torch.from_numpy(np.abs(g[f"s0:g:{k}"]) > 1e-4 * G)
+        assert d[live].numel() == 0 or d[live].max().item() < 3e-2 * lr, (k, d[live].max().item())
+    # ---- overflow: 2^44 puts d loss / d eps ~ 1e-4 * 1.8e13 far outside the fp16 window of the weight-gradient operands
+    before = (tr._t.w.clone(), tr.m.clone(), tr.v.clone(), tr.ema.clone(), tr.opt_step, tr.ema_sched.step, tr._t.loss_scale)
+    tr._t.set_loss_scale(2.0 ** 44)
+    tr.loss_and_gradients(torch.from_numpy(g["s0:state"]).to(dev), torch.from_numpy(g["s0:t"]).to(dev), torch.from_numpy(g["s0:noise"]).to(dev))
+    assert tr.optimizer_step() is False
+    assert tr._t.loss_scale == 2.0 ** 43 and tr.good_steps == 0
+    after = (tr._t.w, tr.m, tr.v, tr.ema, tr.opt_step, tr.ema_sched.step)
+    assert all(torch.equal(a, b) if torch.is_tensor(a) else a == b for a, b in zip(before[:6], after))
+    tr.check_gradient_range()                                     # the poison kernel consumed the gradient bit; no activation bit was raised
+    # growth: after `scale_growth_interval` clean steps the scale doubles
+    settled = float(before[-1])
+    # ---- the checkpoint carries the scaler in torch.cuda.amp.GradScaler.state_dict()'s layout (the reference stores accelerate's, :951)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        tr.results_path = __import__("pathlib").Path(d)
+        tr._t.set_loss_scale(2.0 ** 17)
+        tr.loss_scale, tr.good_steps = 2.0 ** 17, 5
+        tr.save(3)
+        sc = torch.load(str(tr.results_path / "model-3.pt"), weights_only=False)["scaler"]
+        assert sc["scale"] == 2.0 ** 17 and sc["_growth_tracker"] == 5 and sc["backoff_factor"] == 0.5 and sc["growth_interval"] == 2000
+        tr2 = _trainer(g, dev, bwd_mode="f16x3", loss_scale="dynamic", results_path=d)
+        tr2.load(3)
+        assert tr2.loss_scale == 2.0 ** 17 and tr2.good_steps == 5
+        tr2._ensure()
+        assert tr2._t.loss_scale == 2.0 ** 17
+    tr._t.set_loss_scale(settled / 2)
+    tr.scale_growth_interval, tr.good_steps = 2, 0
+    for _ in range(2):
+        tr.loss_and_gradients(torch.from_numpy(g["s0:state"]).to(dev), torch.from_numpy(g["s0:t"]).to(dev), torch.from_numpy(g["s0:noise"]).to(dev))
+        assert tr.optimizer_step() is True
+    assert tr._t.loss_scale == settled
 
 
 def test_training_step_is_bit_reproducible_and_inference_sees_the_trained_weights(dev):
@@ -245,7 +332,7 @@ def test_conv_weight_gradient(case, dev):
     nb = lib.dpc_conv_wgrad_workspace_bytes(Ci, N, *k, B * Fr * Ho)
     ws = L.workspace(nb, dev)
     L.check(lib.dpc_conv_wgrad_cl(L.ptr(xd), L.ptr(dyd), L.ptr(dw), B, Fr, H, W, Ci, Ho, Wo, N, *k, *st, *pd, 0, Ci + 3, 2, 1.0,
-                                  2.0 ** 20 if f16 else 0.0, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+                                  2.0 ** 20 if f16 else 0.0, 0.0, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
     got = dw.cpu()
     assert torch.all(got[:, :2] == 7.0) and torch.all(got[:, 2 + Ci:] == 7.0)      # nothing outside the slice is touched
     err = (got[:, 2:2 + Ci] - ref).abs().max().item() / ref.abs().max().item()
@@ -268,7 +355,7 @@ def test_f16x3_weight_gradient_saturation_is_reported(dev):
 
     def run(xx, dd):
         L.check(lib.dpc_conv_wgrad_cl(L.ptr(xx), L.ptr(dd), L.ptr(dw), B, Fr, H, W, Ci, H, W, N, 3, 3, 3, 1, 1, 1, 1, 1, 0, Ci, 0, 1.0,
-                                      2.0 ** 20, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+                                      2.0 ** 20, 0.0, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
         return lib.dpc_train_range_status(1, L.stream())
     lib.dpc_train_range_status(1, L.stream())                     # clear whatever an earlier test left
     assert run(x, dy) == 0

@@ -32,8 +32,10 @@ def build_parser():
                         help="folder to save training checkpoints")
     # host-side extras
     parser.add_argument("--synthetic", default=False, type=lambda s: str(s).lower() in ("1", "true", "yes"))
-    parser.add_argument("--bwd_mode", default="x6", choices=["x6", "f16x3", "f32"])
-    parser.add_argument("--loss_scale", default=1.0, type=float)
+    parser.add_argument("--bwd_mode", default="f16x3", choices=["x6", "f16x3", "f32"])
+    parser.add_argument("--loss_scale", default=None, type=lambda v: v if v == "dynamic" else float(v),
+                        help="power of two, or 'dynamic' (start 2^20, halve on overflow, double every 2000 clean steps); default: dynamic "
+                             "for --bwd_mode f16x3, 1 for the exact modes")
     parser.add_argument("--save_and_sample_every", default=10000, type=int)
     parser.add_argument("--image_size", default=64, type=int)
     parser.add_argument("--seed", default=0, type=int)
