@@ -1,7 +1,7 @@
 """Implicit-GEMM micro-bench on the GPU box (through the C ABI: dpc_conv_pack / dpc_conv_run), the shapes of both workloads:
 the Burgers U-Net's GEMM-shaped deep levels (3x3 on 4x32 / 2x16 / 1x8 images, batch 256) and the smoke U-Net's 1x1x1 projections.
 Each shape: f16x3 (default) against the exact x6 mode (max error relative to the output range), median of `reps` event-timed runs.
-  gpurun -- 'python tools/bench_igemm.py [burgers|smoke|all] [reps]'
+  gpurun -- 'python tools/bench_igemm.py [burgers|smoke|flat|all] [reps]'
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +24,16 @@ BURGERS = [
     ("b 2x16 1024->512 1x1", 256, 2, 16, 512, 512, 512, 1, False),
     ("b 8x64 128->384 1x1", 256, 8, 64, 128, 0, 384, 1, False),
 ]
+FLAT = [   # the (1,3,3) halo-kernel shapes (H % 8 == 0, W % 8 == 0): Burgers levels 0 / 1, the jellyfish surrogates at J128
+    ("b 16x128 64->64 3x3", 256, 16, 128, 64, 0, 64, 3, False),
+    ("b 16x128 128->64 3x3 (concat)", 256, 16, 128, 64, 64, 64, 3, False),
+    ("b 8x64 64->64 3x3", 256, 8, 64, 64, 0, 64, 3, False),
+    ("b 8x64 128->64 3x3 (concat)", 256, 8, 64, 64, 64, 64, 3, False),
+    ("j 128x128 64->64 3x3", 320, 128, 128, 64, 0, 64, 3, False),
+    ("j 64x64 128->128 3x3", 320, 64, 64, 128, 0, 128, 3, False),
+    ("j 32x32 256->256 3x3", 320, 32, 32, 256, 0, 256, 3, False),
+    ("j 16x16 512->512 3x3", 320, 16, 16, 512, 0, 512, 3, False),
+]
 SMOKE = [
     ("s 16x16 256->256 1x1 +res", 512, 16, 16, 256, 0, 256, 1, True),
     ("s 16x16 256->384 1x1", 512, 16, 16, 256, 0, 384, 1, False),
@@ -38,7 +48,7 @@ SMOKE = [
     ("s 16x16 128->128 2x2 (ConvT class)", 512, 16, 16, 128, 0, 128, 2, False),
     ("s 64x64->32x32 64->64 4x4 s2", 512, 64, 64, 64, 0, 64, 4, False),
 ]
-shapes = (BURGERS if which in ("burgers", "all") else []) + (SMOKE if which in ("smoke", "all") else [])
+shapes = (BURGERS if which in ("burgers", "all") else []) + (SMOKE if which in ("smoke", "all") else []) + (FLAT if which in ("flat", "all") else [])
 g = torch.Generator(device="cpu").manual_seed(0)
 for name, images, H, W, C0, C1, N, k, res in shapes:
     K = C0 + C1
