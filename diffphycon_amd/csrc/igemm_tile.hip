@@ -206,8 +206,7 @@ static int launch_t(const IgemmParams& p, const void* wp6, hipStream_t s) {
         const int o = p.tdh[t] * p.Wi + p.tdw[t];
         lo = std::min(lo, o); hi = std::max(hi, o);
     }
-    static const int pad = debug_switch("DPC_DBG_LDS_PAD_T", 0);          // (r04 experiment: extra bytes behind the tile's LDS image)
-    const size_t lds = (size_t)(BM + hi - lo + 1) * (KCH * 128 + 16) + pad;      // what this launch needs (occupancy follows the image width)
+    const size_t lds = (size_t)(BM + hi - lo + 1) * (KCH * 128 + 16);            // what this launch needs (occupancy follows the image width)
     const unsigned nwg = (unsigned)((p.M + BM - 1) / BM);
     hipLaunchKernelGGL((igemm3t_kernel<KCH, 4, MT, NT, 2, 2, BM>), dim3(nwg), dim3(256), lds, s, p, (const unsigned char*)wp6);
     DPC_LAUNCH_CHECK();
