@@ -49,6 +49,19 @@ struct DeviceOnce {
 // Remainder plane of the 2-way fp16 operand split: the packed pair (f16(x0 - h.lo), f16(x1 - h.hi)) for a packed f16 pair h, as ONE
 // v_fma_mix per element (f32 * 1.0 - f16 -> f16).  x - h is exact in fp32, so this rounds exactly as convert -> subtract -> convert
 // does, in a third of the VALU instructions.
+// Hardware saturation of fp16 conversions (r04; f16x3.h has the long form of this note): with MODE.FP16_OVFL set an fp16 RESULT that
+// overflows becomes +-65504 instead of inf, so the v_med3 in front of every operand conversion of the f16x3 loaders is not needed.
+// A kernel calls fp16_ovfl_enable() once at its top and converts sat16x(x) instead of a clamped x.  -DDPC_FP16_OVFL=0: software clamp.
+#ifndef DPC_FP16_OVFL
+#define DPC_FP16_OVFL 1
+#endif
+__device__ __forceinline__ void fp16_ovfl_enable() {
+    if (DPC_FP16_OVFL) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);       // hwreg(HW_REG_MODE, offset 23, width 1) = 1
+}
+__device__ __forceinline__ float sat16x(float x) {
+    return DPC_FP16_OVFL ? x : __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
+}
+
 __device__ __forceinline__ unsigned f16_sub_pk(float x0, float x1, unsigned h) {
     unsigned r;
     asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"

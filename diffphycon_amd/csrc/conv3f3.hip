@@ -52,7 +52,7 @@ __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__built
 
 // 4 floats (already scaled) -> two (2 x u32) packs of 4 fp16 each: h1 = fp16(x), h2 = fp16(x - h1)
 __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
-    const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
+    const float x0 = sat16x(v.x), x1 = sat16x(v.y), x2 = sat16x(v.z), x3 = sat16x(v.w);
     p1.x = cvt_pk_f16(x0, x1);
     p1.y = cvt_pk_f16(x2, x3);
     p2.x = f16_sub_pk(x0, x1, p1.x);
@@ -66,6 +66,7 @@ __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
 // WR: weight ring depth (divides 27), AD: A-fragment ring depth (2 or 3).
 template <int BN, int WM, int WR, int AD>
 __global__ __launch_bounds__(256, 2) void conv3f3_kernel(Conv3hParams p) {
+    fp16_ovfl_enable();                                 // (common.h: operand conversions saturate in hardware)
     static_assert(27 % WR == 0 && (AD == 2 || AD == 3), "static ring indices across channel chunks");
     using namespace f3;
     constexpr int WN = 4 / WM;
@@ -291,6 +292,7 @@ constexpr int TH8 = 8, HH8 = TH8 + 2;
 // kernel choice never depends on the batch size.
 template <int BN, int KD, bool PERSIST = false>
 __global__ __launch_bounds__(256, 1) void conv3f3b_kernel(Conv3hParams p) {
+    fp16_ovfl_enable();                                 // (common.h: operand conversions saturate in hardware)
     using namespace f3b;
     constexpr int WM = BN == 64 ? 4 : 2, WN = 4 / WM, MT = 4, NT = 2;
     constexpr int TF = 2 * WM, HF = TF + KD - 1, NTAPS = 9 * KD, FPAD = KD / 2;

@@ -34,6 +34,7 @@ namespace dpc {
 // frame halo) -- few taps and small K make the per-tile prologue / epilogue of conv3f3b the larger part of its time there.
 template <int BN, int KD>
 __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
+    fp16_ovfl_enable();                                 // (common.h: operand conversions saturate in hardware)
     using namespace f3c;
     constexpr int WM = BN == 64 ? 4 : 2, WN = 4 / WM, MT = 4, NT = 2;
     constexpr int TF = 2 * WM, HF = TF + KD - 1, NTAPS = 9 * KD, FPAD = KD / 2;

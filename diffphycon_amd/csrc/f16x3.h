@@ -23,13 +23,8 @@ __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__built
 // are the identity / unsaturated forms under DPC_FP16_OVFL (default) and the software clamp otherwise (A/B: -DDPC_FP16_OVFL=0).
 // In range the results are bit-identical; beyond it (outside the f16x3 contract, watched by the range sentinel) hi = +-65504 either
 // way and the remainder plane holds f16(x - hi) instead of 0.  dpc_selftest_fp16_clamp (api.hip) checks the mode bit on the device.
-#ifndef DPC_FP16_OVFL
-#define DPC_FP16_OVFL 1
-#endif
-constexpr bool HW_SAT = DPC_FP16_OVFL != 0;
-__device__ __forceinline__ void hw_sat_enable() {
-    if (HW_SAT) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);        // hwreg(HW_REG_MODE, offset 23, width 1) = 1
-}
+constexpr bool HW_SAT = DPC_FP16_OVFL != 0;                 // (common.h: fp16_ovfl_enable / sat16x, shared with the conv / stem loaders)
+__device__ __forceinline__ void hw_sat_enable() { fp16_ovfl_enable(); }
 __device__ __forceinline__ float sat16h(float x) { return HW_SAT ? x : sat16(x); }
 
 // 8 floats (already scaled and inside +-65504) -> two f16x8 planes (plane 0 = leading term)

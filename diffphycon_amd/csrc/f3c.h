@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
 }
 __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
 __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
-    const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
+    const float x0 = sat16x(v.x), x1 = sat16x(v.y), x2 = sat16x(v.z), x3 = sat16x(v.w);
     p1.x = cvt_pk_f16(x0, x1);
     p1.y = cvt_pk_f16(x2, x3);
     p2.x = f16_sub_pk(x0, x1, p1.x);

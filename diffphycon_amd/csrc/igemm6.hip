@@ -238,7 +238,7 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
 }
 __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
 __device__ __forceinline__ void split2(const f32x4 v, uint2& p1, uint2& p2) {
-    const float x0 = sat16(v.x), x1 = sat16(v.y), x2 = sat16(v.z), x3 = sat16(v.w);
+    const float x0 = sat16x(v.x), x1 = sat16x(v.y), x2 = sat16x(v.z), x3 = sat16x(v.w);
     p1.x = cvt_pk_f16(x0, x1);
     p1.y = cvt_pk_f16(x2, x3);
     p2.x = f16_sub_pk(x0, x1, p1.x);
@@ -257,6 +257,7 @@ typedef _Float16 f16x8_g __attribute__((ext_vector_type(8)));
 // and a spilling build of this kernel has twice given batch-size dependent results at full size.
 template <int BN, bool VEC>
 __global__ __launch_bounds__(256, (BN == 64 ? 4 : 2)) void igemm3_kernel(IgemmParams p, const unsigned char* __restrict__ wp6) {
+    fp16_ovfl_enable();                                 // (common.h: operand conversions saturate in hardware)
     using namespace g3;
     constexpr int NT = BN / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];

@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
 }
 __device__ __forceinline__ float sat16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
 __device__ __forceinline__ void split2_2(float a, float b, unsigned& p1, unsigned& p2) {
-    a = sat16(a); b = sat16(b);
+    a = sat16x(a); b = sat16x(b);
     p1 = cvt_pk_f16(a, b);
     p2 = f16_sub_pk(a, b, p1);
 }
@@ -73,6 +73,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the MFMAs; an A fragment is two adjacent 8-byte slots (8-byte aligned: ds_read2_b64), rows are 128 B and not rotated.
 template <bool H3, int CS = 8>
 __global__ __launch_bounds__(256, 2) void stem7x6_kernel(StemParams p, const unsigned char* __restrict__ wp6) {
+    fp16_ovfl_enable();                                 // (common.h: operand conversions saturate in hardware)
     using namespace s7;
     static_assert(CS == 8 || (CS == 4 && H3), "4-channel slots exist for the f16x3 form only");
     constexpr int SLOTB = CS * 2, ROWB = SLOTS * SLOTB, PLANEB = HF * HH * ROWB, KS = CS / 2;     // (shadow the 8-channel constants of s7)
@@ -261,6 +262,7 @@ constexpr int PLANEB = s7::HF * s7::HH * ROWB;             // 9 600 B per (chann
 
 template <int NCP>
 __global__ __launch_bounds__(256, 2) void stem7p_kernel(StemParams p, const unsigned char* __restrict__ wp6) {
+    fp16_ovfl_enable();                                 // (common.h: operand conversions saturate in hardware)
     using namespace s7;
     constexpr int ROWB = s7p::ROWB, PLANEB = s7p::PLANEB;
     constexpr int WROWB = 64;                                     // packed weight bytes per (step, n): 2 planes x 16 fp16
