@@ -29,6 +29,7 @@ def note_error(name, err):
     if path:
         import json
         test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         with open(path, "a") as f:
             f.write(json.dumps({"test": test, "name": name, "err": float(err)}) + "\n")
     return err

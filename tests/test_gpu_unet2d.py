@@ -89,6 +89,33 @@ def test_fused_linear_attention_equals_the_unfused_composition(dev, monkeypatch)
     assert note_error("unet2d fused vs unfused linear attention", rel(outs["0"], outs["1"])) < 1.6e-6
 
 
+@pytest.mark.parametrize("hw", [(8, 20), (16, 24)])
+def test_fused_linear_attention_on_ragged_token_counts(hw, dev, monkeypatch):
+    """The fused block masks the tokens of its last 32-token tile: 8 x 20 images give 160 tokens (5 tiles) at C = 64 and, one level
+    down, 4 x 10 = 40 tokens (1.25 tiles); 16 x 24 gives 384 / 96.  Against the CPU oracle (bar 1e-4; asserted at 3x the measured error) and against
+    the unfused composition."""
+    from conftest import note_error
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from oracle import unet2d as U
+    mults = (1, 2)
+    cfg = U.Unet2DConfig(dim=64, dim_mults=mults, resnet_block_groups=8)
+    sd = U.synthetic_state_dict(cfg, seed=11)
+    H, W = hw
+    x = torch.randn(3, 2, H, W, generator=torch.Generator().manual_seed(6))
+    t = torch.tensor([3, 500, 998])
+    with torch.no_grad():
+        ref = U.unet2d_forward(sd, cfg, x, t)
+    outs = {}
+    for unfused in ("0", "1"):
+        monkeypatch.setenv("DPC_UNFUSED_ATTN", unfused)
+        m = Unet2D(dim=64, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=8)
+        m.load_state_dict(sd)
+        outs[unfused] = m.to(dev)(x.to(dev), t.to(dev)).cpu()
+    assert note_error(f"unet2d ragged {H}x{W} fused vs oracle", rel(outs["0"], ref)) < 4e-6          # measured 1.2e-6 (profiles/r04_w_tol2.jsonl)
+    assert note_error(f"unet2d ragged {H}x{W} fused vs unfused", rel(outs["0"], outs["1"])) < 2e-6          # measured 6.4e-7
+    assert torch.isfinite(outs["0"]).all()
+
+
 def test_micro_batching_is_exact(dev):
     g = load_golden("unet2d_a")
     x = torch.randn(5, 2, 16, 32, generator=torch.Generator().manual_seed(0)).to(dev)
