@@ -362,6 +362,22 @@ GaussianDiffusion.p_losses = _gd_p_losses
 GaussianDiffusion.forward = _gd_forward
 
 
+def loss_scale_update(scale, good_steps, grad_norm, growth_interval=2000, max_scale=2.0 ** 24):
+    """torch.cuda.amp.GradScaler's rule (what accelerate applies for the reference's Trainer(fp16=True), diffusion_2d_smoke.py:871-874)
+    on the one number every rank holds after the gradient all-reduce: -> (apply the optimizer step?, new scale, new clean-step count).
+    A non-finite norm (an overflow on ANY rank: include/dpc.h dpc_train_range_poison) skips the step and halves the scale; `growth_interval`
+    clean steps in a row double it."""
+    import math
+    if not math.isfinite(grad_norm):
+        if scale <= 1.0:
+            raise FloatingPointError("dynamic loss scale: gradients are not finite at loss scale 1")
+        return False, scale / 2, 0
+    good_steps += 1
+    if good_steps % growth_interval == 0 and scale < max_scale:
+        scale *= 2
+    return True, scale, good_steps
+
+
 class _EmaSchedule:
     """When and how `EMA.update()` of ema-pytorch 0.7.3 (environment.yaml:41; Trainer :920 passes beta = ema_decay,
     update_every = ema_update_every; the package defaults update_after_step 100, inv_gamma 1, power 2/3, min_value 0) touches
@@ -593,19 +609,14 @@ class Trainer(object):
         p, n = T.ctx.ws(L.dpc_reduce_workspace_bytes())
         _lib.check(L.dpc_l2_norm(_lib.ptr(g), g.numel(), ginv, _lib.ptr(self.norm), p, n, _lib.stream()))
         if self.dynamic_scale:
-            import math
-            if not math.isfinite(float(self.norm.item())):          # the ONE host read of a step in this mode
+            apply, scale, self.good_steps = loss_scale_update(T.loss_scale, self.good_steps, float(self.norm.item()),      # the ONE host read
+                                                              self.scale_growth_interval)                            # of a step in this mode
+            if scale != T.loss_scale:
+                T.set_loss_scale(scale)
+                self.loss_scale = scale
+            if not apply:
                 self.skipped_steps += 1
-                self.good_steps = 0
-                if T.loss_scale <= 1.0:
-                    raise FloatingPointError("dynamic loss scale: gradients are not finite at loss scale 1")
-                T.set_loss_scale(T.loss_scale / 2)
-                self.loss_scale = T.loss_scale
                 return False                                         # weights, moments, EMA and both schedules stay where they were
-            self.good_steps += 1
-            if self.good_steps % self.scale_growth_interval == 0 and T.loss_scale < 2.0 ** 24:
-                T.set_loss_scale(T.loss_scale * 2)
-                self.loss_scale = T.loss_scale
         mode, wgt = self.ema_sched.next()
         lr = self._lr()
         self.opt_step += 1

@@ -78,3 +78,51 @@ def test_two_rank_gradient_allreduce_keeps_replicas_bit_identical(tmp_path):
         d = (w0[k] - torch.from_numpy(g[f"s1:w:{k}"])).abs()
         live = torch.from_numpy(abs(g[f"s0:g:{k}"]) > 1e-4 * float(ref.abs().max()))
         assert d[live].numel() == 0 or d[live].max().item() < 3e-5, k
+
+
+def _skip_worker(rank, world, port, out_dir):
+    """The skip protocol of the dynamic loss scale (Trainer.optimizer_step) on the product's collective: rank 1's gradient overflowed in
+    step 0 -- dpc_train_range_poison would have written +inf into its g[0] --, the SUM all-reduce carries it to rank 0, both ranks see a
+    non-finite norm, both skip and halve; step 1 is clean on both and is applied."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffphycon_amd import parallel
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import loss_scale_update
+    torch.manual_seed(7)                                  # same "weights" on both ranks
+    w = torch.randn(1000)
+    scale, good, log = 2.0 ** 20, 0, []
+    for step in range(3):
+        g = torch.full((1000,), 1e-3 * (rank + 1) * scale)
+        if step == 0 and rank == 1:
+            g[0] = float("inf")                           # what the poison kernel does on the rank that overflowed
+        n = parallel.allreduce_sum_(g)
+        norm = float(torch.linalg.vector_norm(g / (scale * n)))
+        apply, scale, good = loss_scale_update(scale, good, norm, growth_interval=2)
+        if apply:
+            w -= 0.1 * g / (scale if step != 2 else scale / 2) / n      # (step 2 grew the scale AFTER its gradients were formed)
+        log.append((apply, scale, good))
+    torch.save({"w": w, "log": log}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_overflow_on_one_rank_skips_the_step_on_every_rank(tmp_path):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_skip_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    assert a["log"] == b["log"] == [(False, 2.0 ** 19, 0), (True, 2.0 ** 19, 1), (True, 2.0 ** 20, 2)]
+    assert torch.equal(a["w"], b["w"])
+
+
+def test_loss_scale_rule():
+    sys.path.insert(0, ROOT)
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import loss_scale_update
+    assert loss_scale_update(2.0 ** 20, 5, float("nan")) == (False, 2.0 ** 19, 0)
+    assert loss_scale_update(2.0 ** 20, 1998, 0.5) == (True, 2.0 ** 20, 1999)
+    assert loss_scale_update(2.0 ** 20, 1999, 0.5) == (True, 2.0 ** 21, 2000)
+    assert loss_scale_update(2.0 ** 24, 1999, 0.5) == (True, 2.0 ** 24, 2000)          # capped
+    with pytest.raises(FloatingPointError):
+        loss_scale_update(1.0, 0, float("inf"))
