@@ -30,6 +30,13 @@ __device__ __forceinline__ float sat16h(float x) { return HW_SAT ? x : sat16(x);
 // 8 floats (already scaled and inside +-65504) -> two f16x8 planes (plane 0 = leading term)
 __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
                                        f16x8 (&o)[2]) {
+#ifdef DPC_DBG_NO_SPLIT       // attribution builds only (tools/attn_ceiling.sh): the operand conversion is skipped, results are INVALID
+    asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+    o[0] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    o[1] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+    return;
+#endif
     uint4 a, b;
     a.x = cvt_pk(v0, v1); a.y = cvt_pk(v2, v3); a.z = cvt_pk(v4, v5); a.w = cvt_pk(v6, v7);
     // remainder plane: one v_fma_mix per element (common.h: f16_sub_pk)
@@ -54,6 +61,10 @@ template <bool SAT>
 __device__ __forceinline__ void split_acc_h(const f32x16& v, float mul, f16x8 (&o)[2][2]) { split_acc<SAT && !HW_SAT>(v, mul, o); }
 
 __device__ __forceinline__ void mfma3(f32x16& acc, const f16x8 (&a)[2], const f16x8 (&b)[2]) {
+#ifdef DPC_DBG_NO_MFMA        // attribution builds only (tools/attn_ceiling.sh): the three matrix instructions are skipped, results are INVALID
+    asm volatile("" : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+    return;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);      // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);

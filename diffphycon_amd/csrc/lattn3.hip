@@ -41,6 +41,7 @@ struct L3 {
 namespace l3 {
 constexpr float SX = 16.f, SWGT = 4096.f, PROJ_DESCALE = 1.f / (SX * SWGT);
 constexpr float SP = 1024.f, SV = 16.f, SC = 16.f, SQ = 4096.f, SO = 16.f;
+constexpr float LOG2E = 1.4426950408889634f, LOG2_SP = 10.f;          // SP = 2^10
 }  // namespace l3
 
 __device__ __forceinline__ int rowmap_l3(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -124,14 +125,14 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         q2 += __shfl_xor(q2, 32, 64);
-        const float inv = 1.0f / sqrtf(q2 / (float)C + 1e-5f);
+        const float inv = SX * (1.0f / sqrtf(q2 / (float)C + 1e-5f));      // (SX = 2^4 folded in: exact)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             f32x4 n[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
-                n[q] = (xr[ks][q] - mean) * inv * g * SX;          // a masked token has x = mean = 0: stays exactly 0
+                n[q] = (xr[ks][q] - mean) * inv * g;               // a masked token has x = mean = 0: stays exactly 0
             }
             split8(sat16h(n[0].x), sat16h(n[0].y), sat16h(n[0].z), sat16h(n[0].w), sat16h(n[1].x), sat16h(n[1].y), sat16h(n[1].z),
                    sat16h(n[1].w), xs[ks]);
@@ -187,18 +188,20 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 float tm = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float kv = kk[r] * PROJ_DESCALE;
+                    // r04: logits in units of log2 (one multiply, as before), probabilities as exp2(k' - (m' - log2 SP)) = e SP: a
+                    // subtraction and one v_exp_f32, and the operand split below needs no multiplier (z carries SP as well)
+                    float kv = kk[r] * (PROJ_DESCALE * LOG2E);
                     if (t * 32 + rowmap_l3(r, hh) >= N) kv = -INFINITY;
                     kk[r] = kv;
                     tm = fmaxf(tm, kv);
                 }
-                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64)) - LOG2_SP;
                 const float m_new = fmaxf(m[hd], tm);
-                const float alpha = (m[hd] == -INFINITY) ? 0.f : __expf(m[hd] - m_new);
+                const float alpha = (m[hd] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m[hd] - m_new);
                 float zs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = __expf(kk[r] - m_new);
+                    const float e = __builtin_amdgcn_exp2f(kk[r] - m_new);
                     kk[r] = e;
                     zs += e;
                 }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
                 for (int r = 0; r < 16; ++r) ctxT[hd][r] *= alpha;
                 f16x8 vs[2][2], es[2][2];
                 split_acc_h<true>(vv, PROJ_DESCALE * SV, vs);
-                split_acc_h<false>(kk, SP, es);
+                split_acc_h<false>(kk, 1.f, es);                // (kk = e SP already)
                 mfma3(ctxT[hd], vs[0], es[0]);                 // ctx^T[e][d]: lane = d, regs = e
                 mfma_keep(ctxT[hd], wk[KS - 1][0], wk[KS - 1][1]);
                 mfma3(ctxT[hd], vs[1], es[1]);
@@ -248,13 +251,13 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
                     const float mw = mz[((hd * 2 + 0) * 8 + w) * 32 + l31];
-                    sc[w] = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                    sc[w] = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - M);
                     Z += mz[((hd * 2 + 1) * 8 + w) * 32 + l31] * sc[w];
                 }
                 // this lane holds ctx[d = l31][e = rowmap(r, hh)]; operand plane position of (row e, k = d):
                 const int d = l31, s = d >> 4, dd = d & 15, kh = (dd >> 2) & 1, ki = (dd & 3) + 4 * (dd >> 3);
                 unsigned short* dst = reinterpret_cast<unsigned short*>(sm + OFF_CTX + (hd * 2 + s) * 2048) + kh * 8 + ki;
-                const float norm = SC / (Z * SV * SP);
+                const float norm = SC / (Z * SV);              // (Z = SP x the sum of the probabilities; the contexts carry SV SP)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = 0.f;
@@ -313,14 +316,14 @@ __global__ __launch_bounds__(512, 1) void lattn3_kernel(LattnParams p, const uns
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                qT[r] *= PROJ_DESCALE;
+                qT[r] *= PROJ_DESCALE * LOG2E;
                 mx = fmaxf(mx, qT[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(qT[r] - mx);
+                const float e = __builtin_amdgcn_exp2f(qT[r] - mx);
                 qT[r] = e;
                 sum += e;
             }

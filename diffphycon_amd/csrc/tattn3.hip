@@ -36,6 +36,7 @@ constexpr int TS = 36;
 constexpr float SX = 16.f, SWGT = 4096.f;
 constexpr float PROJ_DESCALE = 1.f / (SX * SWGT);  // accumulator -> true value of a projection
 constexpr float SQK = 16.f, SP = 1024.f, SV = 16.f, SO = 16.f;
+constexpr float LOG2E = 1.4426950408889634f, LOG2_SP = 10.f;          // SP = 2^10
 }  // namespace t3
 
 size_t tattn3_qkv_bytes(int C) { return (size_t)4 * 3 * (C / 16) * 2048; }
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             cosL[r * TS + c] = r < F ? p.rot_cos[r * 32 + c] : 1.f;
             sinL[r * TS + c] = r < F ? p.rot_sin[r * 32 + c] : 0.f;
         }
-        for (int q = tid; q < NH * 32 * 32; q += 512) biasL[(q >> 5) * TS + (q & 31)] = p.bias32[HD0 * 1024 + q];
+        // (r04: the bias enters the softmax as an exponent of two -- scores and bias carry log2(e), one v_exp_f32 per probability)
+        for (int q = tid; q < NH * 32 * 32; q += 512) biasL[(q >> 5) * TS + (q & 31)] = p.bias32[HD0 * 1024 + q] * LOG2E;
     }
     __syncthreads();
 
@@ -178,14 +180,14 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
                     q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
                 }
             q2 += __shfl_xor(q2, 32, 64);
-            const float inv = 1.0f / sqrtf(q2 / (float)C + 1e-5f);
+            const float inv = SX * (1.0f / sqrtf(q2 / (float)C + 1e-5f));      // (SX = 2^4 folded in: exact)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 f32x4 n[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
-                    n[q] = (xr[ks][q] - mean) * inv * g * SX;      // a masked token has x = mean = 0: stays exactly 0
+                    n[q] = (xr[ks][q] - mean) * inv * g;           // a masked token has x = mean = 0: stays exactly 0
                 }
                 split8(sat16h(n[0].x), sat16h(n[0].y), sat16h(n[0].z), sat16h(n[0].w), sat16h(n[1].x), sat16h(n[1].y),
                        sat16h(n[1].z), sat16h(n[1].w), xs[ks]);
@@ -230,17 +232,18 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             for (int jj = 0; jj < 4; ++jj) {
                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosL + 32 * jj);
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinL + 32 * jj);
-                const float qm = qscale * (PROJ_DESCALE * SQK), km = PROJ_DESCALE * SQK;
-                const float q0 = qT[4 * jj] * qm, q1 = qT[4 * jj + 1] * qm, q2 = qT[4 * jj + 2] * qm, q3 = qT[4 * jj + 3] * qm;
-                qT[4 * jj] = __fadd_rn(__fmul_rn(q0, c4.x), __fmul_rn(-q1, s4.x));
-                qT[4 * jj + 1] = __fadd_rn(__fmul_rn(q1, c4.y), __fmul_rn(q0, s4.y));
-                qT[4 * jj + 2] = __fadd_rn(__fmul_rn(q2, c4.z), __fmul_rn(-q3, s4.z));
-                qT[4 * jj + 3] = __fadd_rn(__fmul_rn(q3, c4.w), __fmul_rn(q2, s4.w));
-                const float k0 = kT[4 * jj] * km, k1 = kT[4 * jj + 1] * km, k2 = kT[4 * jj + 2] * km, k3 = kT[4 * jj + 3] * km;
-                kT[4 * jj] = __fadd_rn(__fmul_rn(k0, c4.x), __fmul_rn(-k1, s4.x));
-                kT[4 * jj + 1] = __fadd_rn(__fmul_rn(k1, c4.y), __fmul_rn(k0, s4.y));
-                kT[4 * jj + 2] = __fadd_rn(__fmul_rn(k2, c4.z), __fmul_rn(-k3, s4.z));
-                kT[4 * jj + 3] = __fadd_rn(__fmul_rn(k3, c4.w), __fmul_rn(k2, s4.w));
+                // r04: one multiply + one fused multiply-add per rotated element (was scale, two multiplies, add); the scale
+                // q * qscale * SQK / (SX SWGT) follows in the operand split below, which multiplies anyway
+                const float q0 = qT[4 * jj], q1 = qT[4 * jj + 1], q2 = qT[4 * jj + 2], q3 = qT[4 * jj + 3];
+                qT[4 * jj] = __builtin_fmaf(q0, c4.x, -(q1 * s4.x));
+                qT[4 * jj + 1] = __builtin_fmaf(q1, c4.y, q0 * s4.y);
+                qT[4 * jj + 2] = __builtin_fmaf(q2, c4.z, -(q3 * s4.z));
+                qT[4 * jj + 3] = __builtin_fmaf(q3, c4.w, q2 * s4.w);
+                const float k0 = kT[4 * jj], k1 = kT[4 * jj + 1], k2 = kT[4 * jj + 2], k3 = kT[4 * jj + 3];
+                kT[4 * jj] = __builtin_fmaf(k0, c4.x, -(k1 * s4.x));
+                kT[4 * jj + 1] = __builtin_fmaf(k1, c4.y, k0 * s4.y);
+                kT[4 * jj + 2] = __builtin_fmaf(k2, c4.z, -(k3 * s4.z));
+                kT[4 * jj + 3] = __builtin_fmaf(k3, c4.w, k2 * s4.w);
             }
             // ---- S^T[j][i] = k_j . q_i   (A = K: lane = key j; B = Q: lane = query i; k index = head dim in register order)
             f32x16 st;
@@ -249,29 +252,31 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             f16x8 qs[2][2];
             {
                 f16x8 kk[2][2];
-                split_acc_h<true>(qT, 1.f, qs);
-                split_acc_h<true>(kT, 1.f, kk);
+                split_acc_h<true>(qT, qscale * (PROJ_DESCALE * SQK), qs);
+                split_acc_h<true>(kT, PROJ_DESCALE * SQK, kk);
                 mfma3(st, kk[0], qs[0]);
                 mfma3(st, kk[1], qs[1]);
             }
-            // ---- bias + softmax over keys (lane-local + partner lane); registers 4jj .. 4jj+3 = keys 8jj + 4hh .. +3
+            // ---- bias + softmax over keys (lane-local + partner lane); registers 4jj .. 4jj+3 = keys 8jj + 4hh .. +3.
+            //      r04: scores in units of log2: s' = s log2(e) + bias log2(e) (one fma), p SP = exp2(s' - (m' - log2 SP)) (sub + v_exp);
+            //      the sum l carries SP as well and the operand split of P needs no multiplier
             float m = -INFINITY;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasL + (hd * 32 * TS + 8 * jj) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float sv = st[4 * jj + e] * (1.f / (SQK * SQK)) + b4[e];
+                    float sv = __builtin_fmaf(st[4 * jj + e], LOG2E / (SQK * SQK), b4[e]);
                     if (!FULL && 8 * jj + 4 * hh + e >= F) sv = -INFINITY;
                     st[4 * jj + e] = sv;
                     m = fmaxf(m, sv);
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64)) - LOG2_SP;
             float l = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(st[r] - m);
+                const float e = __builtin_amdgcn_exp2f(st[r] - m);
                 st[r] = e;
                 l += e;
             }
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             {
                 f16x8 vs[2][2];
                 split_acc_h<true>(vv, PROJ_DESCALE * SV, vs);
-                split_acc_h<false>(st, SP, ps);
+                split_acc_h<false>(st, 1.f, ps);                 // (st = p SP already)
                 mfma3(oT, vs[0], ps[0]);
                 mfma_keep(oT, qs[0][0], qs[0][1]);
                 mfma3(oT, vs[1], ps[1]);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             //      normalisation, the descale of P and V and the pre-scale of O are one multiplier
             {
                 f16x8 os[2][2];
-                split_acc_h<true>(oT, (SO / (SP * SV)) / l, os);
+                split_acc_h<true>(oT, (SO / SV) / l, os);             // (l = SP x the sum of the probabilities)
                 f16x8 wo[2 * NTC][2];
 #pragma unroll
                 for (int g = 0; g < 2 * NTC; ++g) {                 // group g = (column tile g / 2, k-step g % 2)
@@ -456,14 +461,14 @@ __global__ __launch_bounds__(256, 1) void tattn3w_kernel(TattnParams p, const un
                     q2 += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
                 }
             q2 += __shfl_xor(q2, 32, 64);
-            const float inv = 1.0f / sqrtf(q2 / (float)C + 1e-5f);
+            const float inv = SX * (1.0f / sqrtf(q2 / (float)C + 1e-5f));      // (SX = 2^4 folded in: exact)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 f32x4 n[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * ks + 8 * hh + 4 * q);
-                    n[q] = (xr[ks][q] - mean) * inv * g * SX;
+                    n[q] = (xr[ks][q] - mean) * inv * g;
                 }
                 split8(sat16h(n[0].x), sat16h(n[0].y), sat16h(n[0].z), sat16h(n[0].w), sat16h(n[1].x), sat16h(n[1].y),
                        sat16h(n[1].z), sat16h(n[1].w), xs[T][ks]);

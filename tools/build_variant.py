@@ -15,7 +15,7 @@ hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 procs, objs = [], []
 for src in B.sources():
     obj = os.path.join(objdir, src.replace(".hip", ".o"))
-    procs.append(subprocess.Popen([hipcc, *B.FLAGS, *extra, "-c", os.path.join(B.CSRC, src), "-o", obj],
+    procs.append(subprocess.Popen([hipcc, *B.FLAGS, *B.SRC_FLAGS.get(src, []), *extra, "-c", os.path.join(B.CSRC, src), "-o", obj],
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     objs.append(obj)
 for p in procs:

@@ -165,7 +165,10 @@ def audit(lines, lds_only=True):
 
 
 def compile_asm(src):
-    p = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-I", CSRC, "-o", "-", os.path.join(CSRC, src)], capture_output=True, text=True)
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    from diffphycon_amd.build import SRC_FLAGS                     # per-file additions of the product build (a later flag wins)
+    p = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *SRC_FLAGS.get(src, []), "-I", CSRC, "-o", "-", os.path.join(CSRC, src)],
+                       capture_output=True, text=True)
     if p.returncode:
         raise SystemExit(p.stderr[-2000:])
     return p.stdout
