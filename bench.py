@@ -99,10 +99,11 @@ def step_roofline(modes, flop_per_step, sec_per_step, note):
             "peak_note": peak_note, "note": note}
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the COMMITTED rocprofv3 --pmc passes (profiles/pmc_traffic.json: FETCH_SIZE
-    doubled per the guide's gfx950 correction, + WRITE_SIZE), or None.  Not measured by this run: PMC needs rocprofv3."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def pmc_traffic(kernel_class, workload="smoke"):
+    """HBM bytes per launch of a kernel class from the COMMITTED rocprofv3 --pmc passes (profiles/pmc_traffic.json for the S64 headline
+    loop, profiles/pmc_traffic_<workload>.json for the burgers / train legs -- tools/pmc_legs.sh: FETCH_SIZE doubled per the guide's
+    gfx950 correction, + WRITE_SIZE), or None.  Not measured by this run: PMC needs rocprofv3."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if workload == "smoke" else f"pmc_traffic_{workload}.json")
     try:
         row = json.load(open(path)).get(kernel_class, {})
     except (OSError, ValueError):
@@ -331,11 +332,12 @@ def timed_loop(ctx, step, steps, warmup, profile=True):
     return hi / steps, lo / steps, prof_all, prof, warm_ms
 
 
-def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_per_step, traffic_scale=1.0, pmc_workload=False):
-    """pmc_workload: the committed PMC passes (profiles/pmc_traffic.json) were taken on the S64 headline loop in the default arithmetic;
-    every other leg (another workload's launch shapes, or another kernel behind the same class name) reports traffic null."""
+def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_per_step, traffic_scale=1.0, pmc_workload=None):
+    """pmc_workload: which committed PMC passes apply -- "smoke" (profiles/pmc_traffic.json: the S64 headline loop in the default
+    arithmetic), "burgers" / "train" (profiles/pmc_traffic_<leg>.json: that leg's own launch shapes), None: no counters were taken for
+    this leg's launches (another shape, or another kernel behind the same class name): traffic null."""
     name, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-    pmc = pmc_traffic if pmc_workload else (lambda _name: None)
+    pmc = (lambda n: pmc_traffic(n, pmc_workload)) if pmc_workload else (lambda _name: None)
     if d["flops"] > 0:
         achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
         peak, peak_note = mfma_roof(name, modes)
@@ -347,9 +349,14 @@ def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_
                 "traffic": pmc(name)}
     if roof["traffic"] is not None:
         roof["traffic"] *= traffic_scale
-    roof["traffic_source"] = ("committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: per launch of an 8-trajectory micro-batch, "
-                              f"scaled x{traffic_scale:g} to this run's launch size), not re-measured by this run"
-                              if roof["traffic"] is not None else None)
+    if roof["traffic"] is None:
+        roof["traffic_source"] = None
+    elif pmc_workload == "smoke":
+        roof["traffic_source"] = ("committed rocprofv3 --pmc passes (profiles/pmc_traffic.json: per launch of an 8-trajectory micro-batch, "
+                                  f"scaled x{traffic_scale:g} to this run's launch size), not re-measured by this run")
+    else:
+        roof["traffic_source"] = (f"committed rocprofv3 --pmc passes of this leg at this batch (profiles/pmc_traffic_{pmc_workload}.json, "
+                                  "tools/pmc_legs.sh: average over the class's launches), not re-measured by this run")
     roof["kernel"], roof["launches"] = name, d["launches"]
     roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
     if prof_all:
@@ -406,7 +413,8 @@ def run_burgers(ctx, args, t_start, batch=256, with_cpu=True, exact=True):
                                   "mults 1-2-4-8-16) + prior Unet2D(1-2-4-8) + fused update",
                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
     if ctx.rank == 0:
-        out["roofline"] = roofline_of(prof, prof_all, modes, sec_e, args.steps, warm_ms, batch * BURGERS_UNIT_GFLOP / 1e3)
+        out["roofline"] = roofline_of(prof, prof_all, modes, sec_e, args.steps, warm_ms, batch * BURGERS_UNIT_GFLOP / 1e3,
+                                      pmc_workload="burgers" if batch == 256 else None)
         out["roofline"]["note"] = "per-kernel events need eager launches: measured on the eager leg (ms_per_step_eager_profiled)"
         out["roofline_step"] = step_roofline(modes, batch * BURGERS_UNIT_GFLOP * 1e9, sec,
                                              f"{batch} x {BURGERS_UNIT_GFLOP} GFLOP (SURVEY.md 8d) per step / ms_per_step")
@@ -472,7 +480,8 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
                                   f"channels) on 64x64 x 32 frames, batch={batch} per GPU, one optimizer step per bench step",
                       "global_batch": ctx.world * batch, "parallelism": f"data-parallel x{ctx.world} (one flat-gradient all-reduce)"}}
     if ctx.rank == 0:
-        out["roofline"] = roofline_of(prof, prof_all, "", sec, args.steps, warm_ms, 3 * batch * TRAIN_FWD_GFLOP / 1e3)
+        out["roofline"] = roofline_of(prof, prof_all, "", sec, args.steps, warm_ms, 3 * batch * TRAIN_FWD_GFLOP / 1e3,
+                                      pmc_workload="train" if batch == 16 else None)
     ctx.log(t_start, f"train: {sec * 1e3:.1f} ms per optimizer step, loss {first:.4f} -> {last:.4f}")
     if bwd_mode == "f16x3":
         # the same step with EXACT backward-data products (bf16x6, loss scale 1: Trainer(bwd_mode="x6"), train_2d_smoke.py --bwd_mode x6;
@@ -830,7 +839,7 @@ def main():
     out = None
     if rank == 0:
         roof = roofline_of(prof, prof_all, modes, sec, args.steps, warm_ms, B * unit_gflop / 1e3,
-                           traffic_scale=(min(mbatch, B) / 8.0) if not s128 else 1.0, pmc_workload=not s128)
+                           traffic_scale=(min(mbatch, B) / 8.0) if not s128 else 1.0, pmc_workload=None if s128 else "smoke")
         cfg_name = ("S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames" if s128 else
                     "S64 (BASELINE.json configs[2]): 2D smoke 64x64 x 32 frames")
         out = {
