@@ -173,7 +173,8 @@ def _timed_cpu_steps(step, budget_s, max_steps=5):
 
 def cpu_baseline(sd_cpu, budget_s):
     """the CPU oracle (the reference's algorithm restated in torch fp32) on the same unit, 1 warm-up +
-    up to 5 timed steps at B=1 and at B=min(8, cores); `value` is the better of the two rates."""
+    up to 5 timed steps at B=1 and at B=min(4, cores) (r04: 8 cost 90 s for one warm-up + one timed step); `value` is the better of
+    the two rates."""
     from oracle import unet3d as O
     from oracle import sampler_smoke as S
     cores = usable_cores()
@@ -182,7 +183,7 @@ def cpu_baseline(sd_cpu, budget_s):
     cw = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=2)
     sched = S.make_schedule(1000, "sigmoid")
     legs = []
-    for B, share in ((1, 0.4), (min(8, cores), 0.6)):
+    for B, share in ((1, 0.4), (min(4, cores), 0.6)):
         if legs and B == legs[0]["B"]:
             break
         g = torch.Generator().manual_seed(1)
@@ -701,7 +702,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (S64 = 64)")
     ap.add_argument("--micro-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of host time for all cpu_baseline legs")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time for all cpu_baseline legs")
     ap.add_argument("--no-extras", action="store_true", help="headline loop only: no exact-mode / burgers / evaluator legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two real end-to-end passes (DDIM-100: ~30 s, DDPM-1000: ~270 s)")
     ap.add_argument("--stub", action="store_true",
