@@ -184,10 +184,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
     store_x(1);
     __syncthreads();
 
-    // The dY fragments (the MFMAs' B operand, re-read from LDS per k-block) keep their registers through the first tap of the next
-    // k-block of the same iteration: six younger MFMAs (common.h: mfma_keep_a -- the accumulators live in AccVGPRs).
-    // Across the loop's back edge the wave drains its MFMAs before the barrier instead (mfma_drain: one accumulator read per chain,
-    // ~1 % of an iteration's 168 MFMAs).
+    // r04: the 28 (k-block, tap) steps of an iteration are one static sequence with the fragments software-pipelined -- a wave is alone
+    // on its SIMD (224 accumulator registers), so every LDS round trip that is not covered by its own MFMAs is idle matrix-pipe time: the
+    // earlier form read a tap's fragments right in front of its six MFMAs (ISA: 4 ds_read, s_waitcnt, 6 MFMAs, 28 times per iteration:
+    // 0.33 of the roof).  Now the x fragments of step s + 1 are requested before the MFMAs of step s into a ring of FOUR static register
+    // sets (28 % 4 == 0: the slot of a step is the same in every iteration, no loop-carried copies), the dY fragments of k-block kb + 1
+    // during tap 3 of k-block kb into the other of TWO sets.  A set is re-loaded two (x) / at least three (dY) steps after its last
+    // reader: >= 6 younger MFMAs even on the wave whose seventh tap does not exist (common.h: the >= 4 rule).
+    // Across the loop's back edge the wave drains its MFMAs before the barrier (mfma_drain: one accumulator read per chain).
     for (int it = 0; it < ngroups; ++it) {
         issue_x(it + 2);
         issue_y(it + 1);
@@ -195,45 +199,51 @@ __global__ __launch_bounds__(256, 1) void wgrad3_kernel(const Wgrad3Params p) {
         const long long pl = plane0 + v0 / H;
         const int h0 = (int)(v0 % H), f = (int)(pl % F);
         const unsigned ybuf = Cf::Y_OFF + (it & 1) * Cf::YBUF;
-        h3::f16x8 b_spent[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int r = kb / KPR, w0 = 16 * (kb % KPR);
-            const int h = h0 + r;
-            const int vrow = it * RPI + r;
-            h3::f16x8 b[2][2];
+        h3::f16x8 bf[2][2][2], af[4][2];
+        auto load_b = [&](int kb, h3::f16x8 (&dst)[2][2]) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int pln = 0; pln < 2; ++pln) {
                     const unsigned o = ybuf + n * 2 * Cf::YPLANE + pln * Cf::YPLANE + kb * 16 * 64 + lane_off;
-                    b[n][pln] = tr_frag(ldsp(o), ldsp(o + 256));
+                    dst[n][pln] = tr_frag(ldsp(o), ldsp(o + 256));
                 }
+        };
+        auto step_live = [&](int st) { const int t = st % 7; return t < 6 || t < ntap; };      // (every wave owns >= 6 taps)
+        auto load_a = [&](int st, h3::f16x8 (&dst)[2]) {
+            if (!step_live(st)) return;
+            const int kb = st / 7, t = st % 7;
+            const int r = kb / KPR, w0 = 16 * (kb % KPR);
+            const int h = h0 + r, vrow = it * RPI + r;
+            const int tap = tap0 + t, d = tap / 9, dh = (tap % 9) / 3, dw = tap % 3;
+            const bool ok = (unsigned)(f + d - 1) < (unsigned)F && (unsigned)(h + dh - 1) < (unsigned)H;
+            const unsigned row_off = ok ? (unsigned)(d * Cf::DFS + ((vrow + dh - 1) & (NS - 1)) * Cf::SLOT + (w0 + dw) * 64)
+                                        : (unsigned)Cf::ZERO_OFF;
+            const unsigned pl_off = ok ? (unsigned)Cf::PLANE : 0u;
+            const unsigned o = row_off + lane_off;
+            dst[0] = tr_frag(ldsp(o), ldsp(o + 256));
+            dst[1] = tr_frag(ldsp(o + pl_off), ldsp(o + pl_off + 256));
+        };
+        load_b(0, bf[0]);
+        load_a(0, af[0]);
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                if (t < 6 || t < ntap) {                         // (every wave owns >= 6 taps: only the seventh is conditional)
-                    const int tap = tap0 + t, d = tap / 9, dh = (tap % 9) / 3, dw = tap % 3;
-                    const bool ok = (unsigned)(f + d - 1) < (unsigned)F && (unsigned)(h + dh - 1) < (unsigned)H;
-                    const unsigned row_off = ok ? (unsigned)(d * Cf::DFS + ((vrow + dh - 1) & (NS - 1)) * Cf::SLOT + (w0 + dw) * 64)
-                                                : (unsigned)Cf::ZERO_OFF;
-                    const unsigned pl_off = ok ? (unsigned)Cf::PLANE : 0u;
-                    const unsigned o = row_off + lane_off;
-                    h3::f16x8 a[2];
-                    a[0] = tr_frag(ldsp(o), ldsp(o + 256));
-                    a[1] = tr_frag(ldsp(o + pl_off), ldsp(o + pl_off + 256));
+        for (int st = 0; st < 28; ++st) {
+            const int kb = st / 7, t = st % 7;
+            if (st + 1 < 28) load_a(st + 1, af[(st + 1) & 3]);
+            if (t == 3 && kb + 1 < 4) load_b(kb + 1, bf[(kb + 1) & 1]);
+            if (step_live(st)) {
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) h3::mfma3(acc[t][n], a, b[n]);
-                    if (t == 0 && kb > 0) {
+                for (int n = 0; n < 2; ++n) h3::mfma3(acc[t][n], af[st & 3], bf[kb & 1][n]);
+                // the previous step's x set and (first tap of a k-block) the previous k-block's dY set stay LIVE behind this step's six
+                // MFMAs: the register allocator may not hand them to the reads that follow (common.h: mfma_keep_a)
+                if (st > 0) mfma_keep_a(acc[t][1], af[(st - 1) & 3][0], af[(st - 1) & 3][1]);
+                if (st > 1) mfma_keep_a(acc[t][0], af[(st - 2) & 3][0], af[(st - 2) & 3][1]);      // (the step before may have been the missing seventh tap)
+                if (t == 0 && kb > 0) {
 #pragma unroll
-                        for (int n = 0; n < 2; ++n) mfma_keep_a(acc[0][n], b_spent[n][0], b_spent[n][1]);
-                    }
+                    for (int n = 0; n < 2; ++n) mfma_keep_a(acc[t][n], bf[(kb - 1) & 1][n][0], bf[(kb - 1) & 1][n][1]);
                 }
             }
-            mfma_order_point();                                  // (the next k-block's MFMAs follow this one's)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int pln = 0; pln < 2; ++pln) b_spent[n][pln] = b[n][pln];
+            __builtin_amdgcn_sched_barrier(0);                   // (one step at a time: left alone the scheduler hoists all 28 steps' reads)
         }
 #pragma unroll
         for (int t = 0; t < 7; ++t)
