@@ -86,6 +86,7 @@ _P, _I, _L, _Z, _D, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_doubl
 
 _SIGNATURES = {
     "dpc_version": (C.c_int, []),
+    "dpc_build_info": (C.c_char_p, []),
     "dpc_last_error": (C.c_char_p, []),
     "dpc_set_mode": (C.c_int, [C.c_char_p, C.c_char_p]),
     "dpc_get_mode": (C.c_char_p, [C.c_char_p]),
@@ -233,8 +234,27 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        _check_build(L)
         _lib = L
     return _lib
+
+
+def _check_build(L):
+    """Correctness of every kernel on a SHARED GPU (a second stream / a second process) rests on one compile flag: no packed fp32 VALU
+    instructions in the device code (build.py stamps what it MEASURED on the linked code objects).  A library -- the
+    in-tree one or a DPC_LIB override -- whose stamp is missing or reports such instructions is refused; DPC_ALLOW_PACKED_FP32=1 loads it anyway
+    (A/B experiments of tools/) and says so."""
+    info = L.dpc_build_info().decode()
+    if "packed_fp32_insts=0;" in info:
+        return
+    msg = (f"{LIB_PATH}: the build stamp says '{info[:60]}...': the device code contains packed fp32 VALU instructions "
+           "(v_pk_{mul,add,fma}_f32), with which kernels return wrong lanes when a second kernel is resident (DESIGN.md 6.2). "
+           "Rebuild with `python -m diffphycon_amd.build --force`")
+    if os.environ.get("DPC_ALLOW_PACKED_FP32") == "1":
+        import warnings
+        warnings.warn(msg + " -- loaded because DPC_ALLOW_PACKED_FP32=1")
+        return
+    raise RuntimeError(msg + ", or set DPC_ALLOW_PACKED_FP32=1 to load it for an experiment")
 
 
 def check(rc):

@@ -31,8 +31,49 @@ NO_SPILL = {"igemm6.hip": ("igemm3_kernel",), "conv3w.hip": ("conv3w_kernel",), 
             "igemm_panel.hip": ("igemm3p_kernel",), "igemm_tile.hip": ("igemm3t_kernel",), "stem7x6.hip": ("stem7p_kernel",), "igemm_img.hip": ("igemm3i_kernel",)}
 
 
+LLVM_BIN = os.environ.get("DPC_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+PACKED_FP32 = r"\bv_pk_(mul|add|fma)_f32\b"
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def scan_packed_fp32(path):
+    """Number of packed fp32 VALU instructions (v_pk_{mul,add,fma}_f32) in the gfx950 code objects of a linked library / object file:
+    the fat binary is unbundled into a temporary directory (llvm-objdump --offloading writes next to its input -- never into lib/)
+    and every device ELF is disassembled.  DESIGN.md 6.2: with these instructions a kernel gives wrong lanes in a few per cent of
+    launches whenever a second kernel is resident; the product library must contain none (`_lib.lib()` checks the stamp below)."""
+    import re
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="dpc_scan_")
+    try:
+        tmp = os.path.join(d, os.path.basename(path))
+        shutil.copy(path, tmp)
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", tmp], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "amdgcn" in f]
+        if not objs:
+            raise RuntimeError(f"{path}: no gfx950 code object found in the fat binary")
+        n = 0
+        for o in objs:
+            asm = subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", o], check=True, stdout=subprocess.PIPE, text=True).stdout
+            n += len(re.findall(PACKED_FP32, asm))
+        return n, len(objs)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _stamp_object(n_packed, n_objs, flags):
+    """lib/build_stamp.o: `dpc_build_info()` (include/dpc.h) -- what the build MEASURED on the linked device code, not what it was asked
+    to do: the count of packed fp32 instructions found by scan_packed_fp32 and the flags of the compile."""
+    src = os.path.join(LIBDIR, "build_stamp.c")
+    text = f"packed_fp32_insts={n_packed};code_objects={n_objs};flags={' '.join(flags)}".replace("\\", "/").replace('"', "'")
+    with open(src, "w") as f:
+        f.write('/* generated by diffphycon_amd/build.py */\nconst char* dpc_build_info(void) { return "' + text + '"; }\n')
+    obj = os.path.join(LIBDIR, "build_stamp.o")
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-O1", "-fPIC", "-c", src, "-o", obj])
+    return obj
 
 
 def _stale():
@@ -79,10 +120,20 @@ def build(force=False, verbose=True):
         out = "\n".join(l for l in out.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in l)
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    # link once without the stamp, measure the device code of THAT file, then link the stamp in (the device code is unchanged by it)
+    pre = LIB + ".prestamp"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", pre, *objs])
+    n_packed, n_objs = scan_packed_fp32(pre)
+    os.remove(pre)
+    stamp = _stamp_object(n_packed, n_objs, [*FLAGS, *extra])
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, stamp]
     if verbose:
         print(" ".join(cmd), flush=True)
+        print(f"device code: {n_objs} code objects, {n_packed} packed fp32 instructions", flush=True)
     subprocess.check_call(cmd)
+    if n_packed and os.environ.get("DPC_ALLOW_PACKED_FP32") != "1":
+        raise RuntimeError(f"{LIB}: {n_packed} packed fp32 VALU instructions in the device code (build flags lost? DESIGN.md 6.2); "
+                           "DPC_ALLOW_PACKED_FP32=1 builds and loads such a library for A/B experiments")
     return LIB
 
 

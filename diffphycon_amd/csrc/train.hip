@@ -45,8 +45,10 @@ struct WgradParams {
     int fpr, nrf, ncf, nru, ncu, nslab;
     long long rows;            // B * F * Ho
     unsigned dy_limit_bits;    // != 0: an operand element with |v| above this (bit pattern of a positive float; Inf / NaN too) raises
-    int* oflag;                //       bit 1 of the gradient-range sentinel (wgrad3.hip) -- the gradient operand is also the input of
-                               //       this layer's f16x3 backward-DATA convolution, which clamps there
+    int* oflag;                //       the gradient-range sentinel (wgrad3.hip): bit 1 for the GRADIENT operand -- it is also the input of
+                               //       this layer's f16x3 backward-DATA convolution, which clamps there -- and bit 0 for the ACTIVATION
+                               //       operand (not a loss-scale matter: include/dpc.h)
+    int x_is_grad;             // ConvTranspose call form: the gradient is passed as x, the activation as dy
 };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             b[i] = bload(rb, eb[i] + (unsigned)pr * bstep);
         }
     };
-    unsigned bmax = 0;                       // largest |operand| bit pattern this lane multiplied (both sides: a ConvTranspose passes its
-                                             // output gradient as x, include/dpc.h)
+    unsigned amax = 0, bmax = 0;             // largest |operand| bit pattern this lane multiplied, per side (a ConvTranspose passes its
+                                             // output gradient as x: p.x_is_grad says which side is the gradient)
     if (row_begin < row_end) {
         // request cursor (row, pr) of step `req`; it runs WG_DEPTH steps ahead of the multiplications and stops at the last step
         // (steps past the end re-request the last one: harmless, never multiplied)
@@ -173,14 +175,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
                     for (int i = 0; i < WG_RB; ++i) bmax = max(bmax, __builtin_bit_cast(unsigned, b_st[d][i]) & 0x7fffffffu);
 #pragma unroll
-                    for (int j = 0; j < WG_RA; ++j) bmax = max(bmax, __builtin_bit_cast(unsigned, a_st[d][j]) & 0x7fffffffu);
+                    for (int j = 0; j < WG_RA; ++j) amax = max(amax, __builtin_bit_cast(unsigned, a_st[d][j]) & 0x7fffffffu);
                 }
                 advance();
                 issue(pr, a_st[d], b_st[d]);             // step q + d + WG_DEPTH into the stage just consumed
             }
         }
     }
-    if (p.dy_limit_bits && bmax > p.dy_limit_bits) atomicOr(p.oflag, 2);
+    if (p.dy_limit_bits) {
+        const unsigned gmax = p.x_is_grad ? amax : bmax, xmax = p.x_is_grad ? bmax : amax;
+        const int bits = (gmax > p.dy_limit_bits ? 2 : 0) | (xmax > p.dy_limit_bits ? 1 : 0);
+        if (bits) atomicOr(p.oflag, bits);
+    }
     const int ldn = p.ncf * 32;
 #pragma unroll
     for (int j = 0; j < WG_RA; ++j) {
@@ -872,6 +878,9 @@ int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, 
                       int kh, int kw, int sh, int sw, int pf, int ph, int pw, int c_valid, int dw_ctot, int dw_coff, float scale,
                       float f16_dy_scale, float dy_abs_limit, int accumulate, void* ws, size_t ws_bytes, dpc_stream_t stream) {
     DPC_REQUIRE(x && dy && dw && ws, "conv_wgrad: null argument");
+    DPC_REQUIRE((accumulate & ~3) == 0, "conv_wgrad: accumulate is a bit set (1: add to dw, 2: x is the gradient operand)");
+    const int x_is_grad = (accumulate >> 1) & 1;
+    accumulate &= 1;
     DPC_REQUIRE(dy_abs_limit >= 0.f, "conv_wgrad: dy_abs_limit must be >= 0 (0 = no check)");
     DPC_REQUIRE(B >= 1 && F >= 1 && C >= 1 && N >= 1 && kf >= 1 && kh >= 1 && kw >= 1 && sh >= 1 && sw >= 1, "conv_wgrad: bad shape");
     DPC_REQUIRE(C % 32 == 0 || 32 % C == 0, "conv_wgrad: input channels must divide or be a multiple of 32 (pad on the host)");
@@ -901,6 +910,7 @@ int dpc_conv_wgrad_cl(const float* x, const float* dy, float* dw, int B, int F, 
     p.ncu = (p.ncf + WG_RB - 1) / WG_RB;
     p.rows = (long long)B * F * Ho;
     p.dy_limit_bits = dy_abs_limit > 0.f ? __builtin_bit_cast(unsigned, dy_abs_limit) : 0u;
+    p.x_is_grad = x_is_grad;
     p.oflag = p.dy_limit_bits ? f16x3_grad_overflow_flag() : nullptr;
     DPC_REQUIRE(!p.dy_limit_bits || p.oflag, "conv_wgrad: cannot allocate the gradient-range sentinel word");
     p.nslab = wgrad_slabs(p.nrf, p.ncf, p.rows);

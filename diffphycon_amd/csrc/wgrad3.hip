@@ -17,6 +17,7 @@
 // group it is multiplied; one barrier per iteration.  Taps that fall outside the tensor read a zero row (no branches in the loop).
 // Partial sums per (slab, unit) are added in fixed order by wgrad3_reduce_kernel, which also undoes the operand scales and writes
 // the reference layout.  Workgroups of one slab sit on the same XCD so that its L2 serves their shared reads.
+#include <mutex>
 #include <algorithm>
 
 #include "common.h"
@@ -312,21 +313,33 @@ static int launch_w(const Wgrad3Params& p, int nblocks, hipStream_t s) {
     return DPC_OK;
 }
 
-static int* g_grad_flag = nullptr;
+// One sentinel word PER DEVICE (the word lives in that device's memory: a process that drives two GPUs must not share -- or fault on --
+// one; keyed like DeviceOnce, by the current device).
+static std::mutex g_grad_flag_mutex;
+static int* g_grad_flag[64] = {};
 int* f16x3_grad_overflow_flag() {
-    if (!g_grad_flag) {
-        if (hipMalloc(&g_grad_flag, sizeof(int)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_grad_flag, 0, sizeof(int));
+    const int d = DeviceOnce::dev();
+    std::lock_guard<std::mutex> lock(g_grad_flag_mutex);
+    if (!g_grad_flag[d]) {
+        int* w = nullptr;
+        if (hipMalloc(&w, sizeof(int)) != hipSuccess) return nullptr;
+        (void)hipMemset(w, 0, sizeof(int));
+        g_grad_flag[d] = w;
     }
-    return g_grad_flag;
+    return g_grad_flag[d];
 }
 int f16x3_grad_overflow_status(int reset, hipStream_t s) {
-    if (!g_grad_flag) return DPC_OK;
+    int* word;
+    {
+        std::lock_guard<std::mutex> lock(g_grad_flag_mutex);
+        word = g_grad_flag[DeviceOnce::dev()];
+    }
+    if (!word) return DPC_OK;
     int v = 0;
-    DPC_HIP(hipMemcpyAsync(&v, g_grad_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPC_HIP(hipMemcpyAsync(&v, word, sizeof(int), hipMemcpyDeviceToHost, s));
     DPC_HIP(hipStreamSynchronize(s));
     if (!v) return DPC_OK;
-    if (reset) DPC_HIP(hipMemsetAsync(g_grad_flag, 0, sizeof(int), s));
+    if (reset) DPC_HIP(hipMemsetAsync(word, 0, sizeof(int), s));
     return fail(DPC_ERR_STATE, std::string("f16x3 weight gradient: ") + ((v & 1) ? "an activation exceeded |x| = 4094" : "") +
                                ((v & 3) == 3 ? " and " : "") + ((v & 2) ? "an output gradient exceeded 65504 / f16_dy_scale" : "") +
                                " (or was not finite) since the last check: the operand was clamped, the step's gradients are not exact; "

@@ -88,69 +88,6 @@ class Burgers1D(Dataset):
         self.rescaler = torch.from_numpy(np.array(peak, dtype=kind))
 
     def __len__(self):
-        return self.u_super.shape[0]
-
-    def __getitem__(self, idx):
-        u_super = self.u_super[idx][::self.ratio_nt][:, :, None]          # (:268)
-        u_base = u_super[:, ::self.ratio_nx, :]
-        return u_base, u_super, self.force[idx], self.x
-
-
-def open_burgers_hdf5(path, mode, base_resolution=(11, 128), super_resolution=(11, 128)):
-    """The file open of HDF5Dataset.__init__ (:222-252), loading the split into memory."""
-    try:
-        import h5py
-    except ImportError as e:
-        raise RuntimeError(f"reading {path} needs h5py, which this image does not ship; use the --synthetic flag, or build a "
-                           "BurgersCache from arrays") from e
-    with h5py.File(path, "r") as f:
-        data = f[mode]
-        base = f"pde_{base_resolution[0]}-{base_resolution[1]}"
-        sup = f"pde_{super_resolution[0]}-{super_resolution[1]}"
-        ratio_nt = int(data[sup].shape[1] / data[base].shape[1])
-        ratio_nx = int(data[sup].shape[2] / data[base].shape[2])
-        return BurgersCache(data[sup][:], data[sup + "_f"][:], data[base].attrs["x"], ratio_nt, ratio_nx)
-
-
-class Burgers1D(Dataset):
-    def __init__(self, dataset="burgers", input_steps=1, output_steps=10, time_interval=1, is_y_diff=False, split="train",
-                 transform=None, pre_transform=None, verbose=False, root_path=None, *, device="cpu", rescaler=None,
-                 stack_u_and_f=False, pad_for_2d_conv=False, partially_observed_fill_zero_unobserved=None, dataset_cache=None,
-                 **kwargs):
-        self.dataset, self.split = dataset, split
-        self.root = "data/" if root_path is None else root_path
-        self.nx = 128
-        self.nt_total, self.nx_total = kwargs["nt_total"], 128
-        self.input_steps, self.output_steps, self.time_interval = input_steps, output_steps, time_interval
-        assert split in ["train", "test"]
-        self.t_cushion_input = input_steps * time_interval if input_steps * time_interval > 1 else 1
-        self.t_cushion_output = output_steps * time_interval if output_steps * time_interval > 1 else 1
-        if dataset_cache is None:
-            if (self.nt_total, self.nx_total) == (11, 128):                # (:61-64)
-                path = os.path.join(self.root, "") + f"{dataset}_{split}.h5"
-            else:
-                path = os.path.join(self.root, "") + f"{dataset}_{split}_nt_{self.nt_total}_nx_{self.nx_total}.h5"
-            dataset_cache = open_burgers_hdf5(path, split, (self.nt_total, self.nx), (self.nt_total, self.nx_total))
-        self.dataset_cache = dataset_cache
-        self.time_stamps = self.nt_total
-        self.n_simu = len(self.dataset_cache)
-        self.time_stamps_effective = (self.time_stamps - self.t_cushion_input - self.t_cushion_output + time_interval) // time_interval
-        self.device = device
-        if rescaler is None:
-            self.calculate_rescaler()
-        else:
-            self.rescaler = rescaler
-        self.stack_u_and_f = stack_u_and_f
-        self.pad_for_2d_conv = pad_for_2d_conv
-        self.fill_zero_unobserved = partially_observed_fill_zero_unobserved
-
-    def calculate_rescaler(self):
-        """data_1d.py:31-35: max |value| over the states and forces of the split."""
-        u = torch.tensor(np.stack([x[1] for x in self.dataset_cache]))
-        f = torch.tensor(np.stack([x[2] for x in self.dataset_cache]))
-        self.rescaler = torch.cat((u.squeeze(), f), dim=1).abs().max()
-
-    def __len__(self):
         return self.n_simu * self.time_stamps_effective
 
     def __getitem__(self, idx):

@@ -732,12 +732,16 @@ class HipDesignGradient:
         convs = [c for c in (_Calibration.convs or ()) if getattr(c, "peak", None) is not None and c.act_scale > 0]
         if not convs:
             return None
-        peaks = torch.cat([c.peak for c in convs]).cpu().tolist()
-        worst = max(p * c.act_scale for p, c in zip(peaks, convs))
+        # scaled peaks as ONE tensor test: Python's max() drops a NaN unless it comes first (every `nan > x` is False), so a NaN peak
+        # of any convolution but the first used to pass
+        peaks = torch.cat([c.peak.reshape(-1)[:1] for c in convs]).double().cpu()
+        scaled = peaks * torch.tensor([c.act_scale for c in convs], dtype=torch.float64)
         for c in convs:
             c.peak = None
-        self.last_headroom = 65504.0 / worst if worst > 0 else float("inf")      # x by which the largest watched tensor could still grow
-        if not math.isfinite(worst) or worst > 65504.0:
+        finite = bool(torch.isfinite(scaled).all())
+        worst = float(scaled.max()) if finite else float("nan")
+        self.last_headroom = 65504.0 / worst if finite and worst > 0 else (float("inf") if finite else 0.0)   # x by which the largest watched tensor could still grow
+        if not finite or worst > 65504.0:
             raise RuntimeError(f"design gradient: a backward tensor left the fp16 window of its convolution (max |x| * scale = {worst:.3g} "
                                "> 65504; scales were fixed on the synthetic calibration input): call calibrate() on representative "
                                "data or set DPC_SURROGATE_MODE=x6")

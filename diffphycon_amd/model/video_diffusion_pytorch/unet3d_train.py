@@ -140,7 +140,7 @@ class _Ctx:
         return y
 
     # ---- weight gradient
-    def wgrad(self, x, dy, wname, geom, B, F, Hi, Wi, Ho, Wo, c_valid=0, ctot=None, coff=0, dw=None):
+    def wgrad(self, x, dy, wname, geom, B, F, Hi, Wi, Ho, Wo, c_valid=0, ctot=None, coff=0, dw=None, x_is_grad=False):
         kd, kh, kw, sh, sw, pd, ph, pw = geom
         Cc, N = x.shape[1], dy.shape[1]
         dw = self.G[wname] if dw is None else dw
@@ -148,7 +148,8 @@ class _Ctx:
         L = _lib.lib()
         p, n = self.ws(L.dpc_conv_wgrad_workspace_bytes(Cc, N, kd, kh, kw, B * F * Ho))
         _lib.check(L.dpc_conv_wgrad_cl(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), B, F, Hi, Wi, Cc, Ho, Wo, N, kd, kh, kw, sh, sw, pd, ph, pw,
-                                       c_valid, ctot, coff, 1.0, self.wgrad_dy_scale, self.dgrad_limit, 0, p, n, _lib.stream()))
+                                       c_valid, ctot, coff, 1.0, self.wgrad_dy_scale, self.dgrad_limit, 2 if x_is_grad else 0, p, n,
+                                       _lib.stream()))
 
 
 class _Pack:
@@ -481,7 +482,7 @@ class _Up:
         x, (B, F, H, W) = self.tape
         self.tape = None
         ctx = self.ctx
-        ctx.wgrad(dy, x, self.wname, _G144, B, F, 2 * H, 2 * W, H, W)
+        ctx.wgrad(dy, x, self.wname, _G144, B, F, 2 * H, 2 * W, H, W, x_is_grad=True)
         ctx.colsum(dy, ctx.G[self.bname])
         return self.d.run(dy, B, F, 2 * H, 2 * W, H, W, act_scale=ctx.act_scale)
 
@@ -561,12 +562,21 @@ class TrainableUnet3D:
         dynamic scaling): nothing on the device depends on it except the two scalars below."""
         self.loss_scale = float(loss_scale)
         assert self.loss_scale > 0 and math.frexp(self.loss_scale)[0] == 0.5, "loss_scale must be a power of two"
-        # the gradient operand of the f16x3 weight-gradient kernel is scaled so that d loss / d eps * 2^24 is what gets split:
-        # d eps ~ 2 (eps - noise) / numel ~ 1e-7 lands at O(1), as it does for the f16x3 backward-data convolutions (loss scale
-        # 2^20 times the operand pre-scale 2^4)
-        # (above 2^20 the operand scale stays 2^4, the forward's: the window |scaled gradient| <= 4094 is then the backward-data
-        #  convolutions' as well, and halving the loss scale widens both)
-        self.ctx.wgrad_dy_scale = max(16.0, (2.0 ** 24) / self.loss_scale) if self.wgrad_mode == "f16x3" else 0.0
+        # Operand scale of the f16x3 weight-gradient kernel's dy (wgrad3 splits dy * wgrad_dy_scale, saturating at 65504).
+        # * backward-data in f16x3 (the Trainer's default, normally under the DYNAMIC loss scale): 2^4, the operand pre-scale of the
+        #   backward-data convolutions -- ONE window |loss_scale * d loss / d conv output| <= 4094 for both kernels, so that a halved
+        #   loss scale widens wgrad3's window as well.  (r04 used max(2^4, 2^24 / loss_scale): below 2^20 the split operand was
+        #   d loss * 2^24 whatever the scale, an overflow at 2^20 -- the scaler's own start -- tripped the sentinel at every
+        #   smaller scale too and the run ended at scale 1 with FloatingPointError: ADVICE r04.)
+        # * exact backward-data products (x6 / f32: a fixed loss scale, 1 by default): 2^24 / loss_scale, which puts
+        #   d eps ~ 2 (eps - noise) / numel ~ 1e-7 at O(1) in front of the split.
+        if self.wgrad_mode != "f16x3":
+            self.ctx.wgrad_dy_scale = 0.0
+        elif self.ctx.bwd_mode == "f16x3":
+            self.ctx.wgrad_dy_scale = 16.0
+        else:
+            self.ctx.wgrad_dy_scale = max(16.0, (2.0 ** 24) / self.loss_scale)
+
     def _blocks(self):
         yield self.init_attn
         for lv in self.downs + self.ups:

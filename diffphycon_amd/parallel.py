@@ -52,17 +52,6 @@ def gather_metric_rows(rows, force=False):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
-def max_scalar_over_ranks(value, device):
-    """MAX of one float over the ranks (no-op without a process group).  Used by the range calibration of the jellyfish
-    design gradient (model/surrogates_hip.py): with the maxima shared, every rank picks the operand scales a single process
-    would pick for the whole batch, so a trajectory's result does not depend on how the batch is sharded."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return value
-    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t.item()
-
-
 def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 

@@ -19,7 +19,18 @@ def test_rescaler_and_length():
     g = load_golden("burgers1d")
     d = Burgers1D(**KW, dataset_cache=_cache(g))
     assert float(d.rescaler) == float(g["rescaler"])
-    assert len(d) == int(g["n_samples"])
+    assert len(d) == int(g["n_samples"]) == len(_cache(g)) * d.time_stamps_effective
+    # a 0-d tensor in the arrays' own precision, as the reference's torch.cat(...).abs().max() (data_1d.py:31-35)
+    assert isinstance(d.rescaler, torch.Tensor) and d.rescaler.dim() == 0
+    assert d.rescaler.dtype == torch.from_numpy(np.asarray(g["u"])).dtype
+
+
+def test_one_definition_per_name():
+    """a botched merge once left two `class Burgers1D` in the module, the first one dead code."""
+    import ast
+    import diffphycon_amd.dataset.data_1d as m
+    names = [n.name for n in ast.parse(open(m.__file__).read()).body if isinstance(n, (ast.ClassDef, ast.FunctionDef))]
+    assert len(names) == len(set(names)), names
 
 
 @pytest.mark.parametrize("tag,kw", [("stack", dict(stack_u_and_f=True, pad_for_2d_conv=True)),

@@ -374,6 +374,93 @@ def test_f16x3_weight_gradient_saturation_is_reported(dev):
     lib.dpc_train_range_status(1, L.stream())
 
 
+def test_a_halved_loss_scale_widens_the_f16x3_weight_gradient_window(dev):
+    """with backward-data in f16x3 the dy operand of wgrad3 is split as (loss_scale * d loss) * 2^4 -- the window of the
+    backward-data convolutions -- so an output gradient that trips the sentinel at 2^20 (the dynamic scaler's start) fits at 2^19.
+    (r04 derived the operand scale as max(2^4, 2^24 / loss_scale): the split operand was d loss * 2^24 at every scale <= 2^20, the
+    halving never helped and the run ended with FloatingPointError at scale 1.)  A wgrad3-eligible shape (W = 16, C % 32 == 0,
+    N % 64 == 0), which the tiny fixture nets never reach."""
+    import ctypes as C
+    from diffphycon_amd import _lib as L
+    lib = L.lib()
+    g = load_golden("train_w")
+    T = _net(g, dev, "f16x3", loss_scale=2.0 ** 20)
+    B, Fr, H, W, Ci, N = 1, 3, 16, 16, 32, 64
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B * Fr * H * W, Ci, generator=gen).to(dev)
+    dy_true = torch.randn(B * Fr * H * W, N, generator=gen) * 1e-4
+    dy_true[37, 5] = 6.0e-3                  # x 2^20 x 2^4 = 100 663 > 65504; x 2^19 x 2^4 = 50 331 fits
+    ws = L.workspace(lib.dpc_conv_wgrad_workspace_bytes(Ci, N, 3, 3, 3, B * Fr * H), dev)
+    dw = torch.empty(N, Ci, 3, 3, 3, device=dev)
+    ref = None
+    status = {}
+    for e in (20, 19, 18):
+        T.set_loss_scale(2.0 ** e)
+        assert T.ctx.wgrad_dy_scale == 16.0
+        dy = (dy_true * 2.0 ** e).to(dev)
+        lib.dpc_train_range_status(1, L.stream())
+        L.check(lib.dpc_conv_wgrad_cl(L.ptr(x), L.ptr(dy), L.ptr(dw), B, Fr, H, W, Ci, H, W, N, 3, 3, 3, 1, 1, 1, 1, 1, 0, Ci, 0, 1.0,
+                                      T.ctx.wgrad_dy_scale, T.ctx.dgrad_limit, 0, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+        status[e] = lib.dpc_train_range_status(1, L.stream())
+        if status[e] == 0:
+            got = dw / 2.0 ** e
+            if ref is None:
+                xd = x.double().cpu().reshape(B, Fr, H, W, Ci).permute(0, 4, 1, 2, 3).requires_grad_(False)
+                w = torch.zeros(N, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+                y = torch.nn.functional.conv3d(xd, w, padding=1)
+                y.backward(dy_true.double().reshape(B, Fr, H, W, N).permute(0, 4, 1, 2, 3))
+                ref = w.grad
+            err = (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 1e-5, (e, err)
+    assert status[20] != 0 and status[19] == 0 and status[18] == 0, status
+    # exact backward-data products keep the r04 rule: the loss scale is fixed and the split operand sits at O(1)
+    Tx = _net(g, dev, "x6", loss_scale=1.0)
+    assert Tx.ctx.wgrad_dy_scale == 2.0 ** 24
+
+
+def test_fp32_weight_gradient_names_the_operand_that_left_the_window(dev):
+    """the fp32 weight-gradient kernel watched both operands with one maximum and raised the GRADIENT bit for an
+    ACTIVATION above the limit -- the dynamic scaler then halved the scale on every step until it died at scale 1 with the wrong
+    message.  Now: activation operand -> bit 0 ("activation", left for dpc_train_range_status, untouched by the poison kernel),
+    gradient operand -> bit 1; the ConvTranspose call form (accumulate bit 1: x is the gradient) swaps the roles."""
+    import ctypes as C
+    from diffphycon_amd import _lib as L
+    lib = L.lib()
+    B, Fr, H, W, Ci, N = 1, 2, 8, 8, 32, 32
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B * Fr * H * W, Ci, generator=gen).to(dev)
+    dy = torch.randn(B * Fr * H * W, N, generator=gen).to(dev)
+    ws = L.workspace(lib.dpc_conv_wgrad_workspace_bytes(Ci, N, 1, 1, 1, B * Fr * H), dev)
+    dw = torch.empty(N, Ci, 1, 1, 1, device=dev)
+    gbuf = torch.zeros(64, device=dev)
+
+    def run(xx, dd, acc):
+        lib.dpc_train_range_status(1, L.stream())
+        L.check(lib.dpc_conv_wgrad_cl(L.ptr(xx), L.ptr(dd), L.ptr(dw), B, Fr, H, W, Ci, H, W, N, 1, 1, 1, 1, 1, 0, 0, 0, 0, Ci, 0, 1.0,
+                                      0.0, 4094.0, acc, C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+        gbuf.zero_()
+        L.check(lib.dpc_train_range_poison(L.ptr(gbuf), L.stream()))          # consumes the gradient bit only
+        poisoned = bool(torch.isinf(gbuf[0]).item())
+        st = lib.dpc_train_range_status(1, L.stream())
+        return poisoned, st, lib.dpc_last_error().decode() if st else ""
+    assert run(x, dy, 0) == (False, 0, "")
+    xb = x.clone()
+    xb[9, 4] = 5000.0
+    poisoned, st, msg = run(xb, dy, 0)
+    assert not poisoned and st != 0 and "activation" in msg and "output gradient" not in msg
+    db = dy.clone()
+    db[9, 4] = 5000.0
+    poisoned, st, msg = run(x, db, 0)
+    assert poisoned and st == 0                                   # the poison kernel cleared the gradient bit
+    # ConvTranspose form: x carries the gradient
+    poisoned, st, msg = run(xb, dy, 2)
+    assert poisoned and st == 0
+    poisoned, st, msg = run(x, db, 2)
+    assert not poisoned and st != 0 and "activation" in msg
+    assert lib.dpc_conv_wgrad_cl(L.ptr(x), L.ptr(dy), L.ptr(dw), B, Fr, H, W, Ci, H, W, N, 1, 1, 1, 1, 1, 0, 0, 0, 0, Ci, 0, 1.0, 0.0, 0.0, 4,
+                                 C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()) != 0
+
+
 def test_column_reductions_and_small_linear_backward(dev):
     import ctypes as C
     from diffphycon_amd import _lib as L
