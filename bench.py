@@ -206,7 +206,8 @@ def cpu_baseline(sd_cpu, budget_s):
     return {"value": best["trajectories_per_s"], "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": f"guided DDPM steps (joint+prior U-Net forward + update), 64x64x32, torch fp32 on {cores} threads: "
                       + "; ".join(f"B={l['B']}: 1 warm-up + {l['timed_steps']} timed, {l['mean_s_per_step']} s/step" for l in legs)
-                      + "; extrapolated x1000 steps",
+                      + "; extrapolated x1000 steps.  Plan of record (BASELINE.md 3): 1 warm-up + 5 timed steps at B=1 and B=min(8, cores) "
+                        f"(~5 minutes of host time); this run used a {budget_s:.0f} s budget (--cpu-budget): the step counts above",
             "legs": legs}
 
 
@@ -244,7 +245,11 @@ def burgers_setup(device, batch, rank, arithmetic=None):
 
 
 def burgers_cpu_baseline(sd_cpu, cond, budget_s):
-    """The POPC recipe on the CPU oracle at B=8 under no_grad: 1 warm-up + up to 5 timed steps inside the budget."""
+    """The POPC recipe on the CPU oracle, once under no_grad and once in the REFERENCE's mode: its sampling loop runs with autograd
+    enabled (diffusion_1d_burgers.py:525 "removed no_grad decorator here"; the denoisers' parameters require grad, so both forwards
+    record a graph, and get_nablaJ :34-49 differentiates the guidance loss with create_graph=True).  BASELINE.md section 3 plans
+    B = 50 with 20 timed steps per mode (52.5 s per step on 8 cores: 35 minutes); inside a bounded sample this runs B = 8 with
+    1 warm-up + up to 5 timed steps per mode and says so.  `value` = the no_grad rate (the faster, i.e. the more favourable to the CPU)."""
     from oracle import unet2d as U
     from oracle import sampler_burgers as S
     cores = usable_cores()
@@ -257,20 +262,97 @@ def burgers_cpu_baseline(sd_cpu, cond, budget_s):
     x0 = torch.randn(B, 2, 16, 128, generator=g)
     z = torch.randn(B, 2, 16, 128, generator=g)
     tb = torch.full((B,), 999, dtype=torch.long)
+    ut = torch.zeros(B, 11, 128)
+    ut[:, 0], ut[:, 10] = cond[0][:B], cond[1][:B]
+    kw = dict(prior_beta=0.9, eta_w=S.scheduler_table("sigmoid_flip")[999], eta_J=S.scheduler_table("cosine")[999])
 
-    def step():
+    def step_nograd():
         x = x0.clone()
         with torch.no_grad():
             S.set_conditions(x, cond[0][:B], cond[1][:B], True)
             e_uw = U.unet2d_forward(sd_cpu[0], c_uw, x, tb)
             e_w = U.unet2d_forward(sd_cpu[1], c_w, S.w_model_input(x), tb)
-            S.p_sample_step(sched, x, 999, e_uw, e_w, z, prior_beta=0.9, eta_w=S.scheduler_table("sigmoid_flip")[999],
-                            eta_J=S.scheduler_table("cosine")[999])
-    warm, times = _timed_cpu_steps(step, budget_s)
-    mean = sum(times) / len(times)
-    return {"value": B / (STEPS_PER_TRAJECTORY * mean), "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"guided DDPM steps (joint+prior Unet2D forward + update) at B={B}, 16x128, torch fp32 no_grad on {cores} "
-                      f"threads: 1 warm-up ({warm:.2f} s) + {len(times)} timed, {mean:.3f} s/step, extrapolated x1000 steps"}
+            S.p_sample_step(sched, x, 999, e_uw, e_w, z, **kw)
+
+    sd_grad = tuple({k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()} for sd in sd_cpu)
+
+    def step_grad():
+        # what the reference's loop pays: both forwards under autograd (graphs of a 136 M-parameter and a 36 M-parameter U-Net
+        # recorded and dropped every step), the guidance gradient by autograd.grad(create_graph=True) on the predicted x0
+        x = x0.clone()
+        S.set_conditions(x, cond[0][:B], cond[1][:B], True)
+        e_uw = U.unet2d_forward(sd_grad[0], c_uw, x, tb)
+        e_w = U.unet2d_forward(sd_grad[1], c_w, S.w_model_input(x), tb)
+
+        def nablaJ(x_start):                                  # get_nablaJ :34-49 over ddpm_guidance_loss (utils.py:1289-1328)
+            x_start.requires_grad_(True)                      # (already part of the denoisers' graph, as in the reference)
+            u, f = x_start[:, 0, :11], x_start[:, 1, :10]
+            m = torch.ones(128)
+            m[32:96] = 0
+            J = 0.0 * ((((u[:, 0] - ut[:, 0]) ** 2 + (u[:, 10] - ut[:, 10]) ** 2) * m).mean(-1)) + 0.0 * (f ** 2).sum((-1, -2)) \
+                + 0.0 * ((u[:, 1:] - u[:, :-1]) ** 2).sum((-1, -2))                          # shipped scripts: all-zero weights
+            return torch.autograd.grad(J, x_start, grad_outputs=torch.ones_like(J), retain_graph=True, create_graph=True,
+                                       allow_unused=True)[0].detach()
+        S.p_sample_step(sched, x, 999, e_uw, e_w, z, grad_fn=nablaJ, **kw)
+
+    legs = {}
+    for name, fn, share in (("no_grad", step_nograd, 0.4), ("grad_enabled", step_grad, 0.6)):
+        warm, times = _timed_cpu_steps(fn, budget_s * share)
+        mean = sum(times) / len(times)
+        legs[name] = {"B": B, "warmup_s": round(warm, 3), "timed_steps": len(times), "mean_s_per_step": round(mean, 4),
+                      "trajectories_per_s": B / (STEPS_PER_TRAJECTORY * mean)}
+    return {"value": legs["no_grad"]["trajectories_per_s"], "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "value_grad_enabled": legs["grad_enabled"]["trajectories_per_s"],
+            "sample": f"guided DDPM steps (joint+prior Unet2D forward + update) at B={B}, 16x128, torch fp32 on {cores} threads, "
+                      + "; ".join(f"{k}: 1 warm-up ({l['warmup_s']} s) + {l['timed_steps']} timed, {l['mean_s_per_step']} s/step" for k, l in legs.items())
+                      + "; extrapolated x1000 steps.  Plan of record (BASELINE.md 3): B=50, 20 timed steps per mode -- reduced to B=8 and <= 5 "
+                        "steps to stay inside the bounded sample; grad_enabled = the reference's own mode (diffusion_1d_burgers.py:525)",
+            "legs": legs}
+
+
+def burgers_fd_leg(ctx, with_cpu, budget_s):
+    """Burgers finite-difference evaluator (generate_burgers.py:207): N = 50 trajectories (the entry script's batch) and
+    N = 256, 10 000 explicit Euler steps in ONE launch, bit-exact vs the reference; CPU = the NumPy oracle, full 10 000 steps at N = 50
+    (BASELINE.md section 3), on one core (NumPy does not thread these element-wise ops)."""
+    import numpy as np
+    from oracle import burgers as OB
+    from diffphycon_amd.evaluators import burgers_numeric_solve_free
+    out = {"metric": "Burgers FD rollouts/s (128 cells, 10 000 Euler steps)", "unit": "rollouts/s", "dtype": "f32 (bit-exact vs the reference)"}
+    for n in (50, 256):
+        u0, f = OB.synthetic_inputs(n, seed=3)
+        ud, fd = torch.from_numpy(u0).to(ctx.device), torch.from_numpy(f).to(ctx.device)
+        burgers_numeric_solve_free(ud, fd, visc=0.01, T=1.0, dt=1e-4, num_t=10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = burgers_numeric_solve_free(ud, fd, visc=0.01, T=1.0, dt=1e-4, num_t=10)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"n{n}"] = {"seconds": dt, "rollouts_per_s": n / dt}
+        if n == 50:
+            keep = (u0, f, got.cpu().numpy())
+    out["value"] = out["n256"]["rollouts_per_s"]
+    if with_cpu:
+        u0, f, got = keep
+        t0 = time.perf_counter()
+        ref = OB.burgers_numeric_solve_free(u0, f, 0.01, 1.0, 1e-4, 10)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 50 / dt, "unit": "rollouts/s", "cores": 1, "kind": "port",
+                               "sample": f"N=50, the full 10 000 steps (BASELINE.md 3) on the NumPy oracle: {dt:.2f} s",
+                               "gpu_equals_cpu_bit_for_bit": bool(np.array_equal(ref, got))}
+    else:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_null_reason"] = "CPU legs run on rank 0 at N=1 only (or --no-cpu-baseline)"
+    return out
+
+
+def _smoke_oracle_rollout(args):
+    """One rollout on the NumPy oracle (a worker of smoke_evaluator's `cores`-process CPU leg)."""
+    import numpy as np
+    from oracle import smoke_solver as O
+    d0, c1, c2, T = args
+    t0 = time.perf_counter()
+    O.solver(O.init_sim_128(), O.init_velocity_(), d0, c1, c2, per_timelength=T)
+    return time.perf_counter() - t0
 
 
 class Ctx:
@@ -304,23 +386,24 @@ class Ctx:
 
 
 def timed_loop(ctx, step, steps, warmup, profile=True):
-    """W untimed warm-up steps (the last one with every kernel class bracketed by events: per-class breakdown), then EXACTLY K
-    timed steps between barrier + synchronize pairs with only the dominant class instrumented (two events per launch cost ~4 %
-    of a step when every launch is bracketed).  -> (max-over-ranks seconds per step, min, prof_all, prof_dom, warm_ms)."""
+    """W untimed warm-up steps (the last one with every kernel class bracketed by events: that picks the dominant class), then
+    EXACTLY K timed steps between barrier + synchronize pairs with only the dominant class instrumented (two events per launch
+    cost ~4 % of a step when every launch is bracketed), then -- OUTSIDE the timed region -- ONE more step with every class
+    bracketed: the per-class breakdown and `kernel_time_fraction_of_step` come from that steady-state step (r04 took them on
+    the last warm-up step, which with --warmup 1 is the very first step of the process: module loads, first-touch allocations;
+    VERDICT r04 weak #3).  -> (max-over-ranks seconds per step, min, prof_all, prof_dom, ms of the breakdown step)."""
     from diffphycon_amd import _lib
-    prof_all, warm_ms = None, None
+    prof_warm = None
     for i in range(warmup):
         last = profile and i == warmup - 1
         if last:
             _lib.profile_begin()
-        tw0 = time.perf_counter()
         step()
         ctx.sync()
-        warm_ms = (time.perf_counter() - tw0) * 1e3
         if last:
-            prof_all = _lib.profile_end()
+            prof_warm = _lib.profile_end()
     ctx.sync()                               # barrier + device sync on both sides of the timed region (also when --warmup 0)
-    dom = max(prof_all.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_all else None
+    dom = max(prof_warm.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof_warm else None
     if profile:
         _lib.profile_begin([dom] if dom else None)
     t0 = time.perf_counter()
@@ -330,7 +413,15 @@ def timed_loop(ctx, step, steps, warmup, profile=True):
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_end() if profile else None
     hi, lo = ctx.reduce(elapsed)
-    return hi / steps, lo / steps, prof_all, prof, warm_ms
+    prof_all, steady_ms = None, None
+    if profile:
+        _lib.profile_begin()
+        tw0 = time.perf_counter()
+        step()
+        ctx.sync()
+        steady_ms = (time.perf_counter() - tw0) * 1e3
+        prof_all = _lib.profile_end()
+    return hi / steps, lo / steps, prof_all, prof, steady_ms
 
 
 def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_per_step, traffic_scale=1.0, pmc_workload=None):
@@ -362,8 +453,8 @@ def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_
     roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
     if prof_all:
         roof["breakdown_ms_per_step"] = {k: round(v["total_ms"], 3) for k, v in sorted(prof_all.items())}
-        roof["breakdown_note"] = ("all classes bracketed by events on the last (untimed) warm-up step; the timed steps bracket "
-                                  "only the roofline kernel class")
+        roof["breakdown_note"] = ("all classes bracketed by events on ONE extra steady-state step run after (outside) the timed region; "
+                                  "the timed steps bracket only the roofline kernel class")
         roof["kernel_time_fraction_of_step"] = sum(v["total_ms"] for v in prof_all.values()) / warm_ms
     else:
         roof["breakdown_ms_per_step"] = {k: round(v["total_ms"] / steps, 3) for k, v in sorted(prof.items())}
@@ -431,8 +522,11 @@ def run_burgers(ctx, args, t_start, batch=256, with_cpu=True, exact=True):
         out["ms_per_step_exact"] = sec_x * 1e3
         out["arithmetic_exact"] = gd_x.model_uw.modes
         del gd_x
-    out["cpu_baseline"] = (burgers_cpu_baseline(sd_cpu, cond, args.cpu_budget * 0.2)
-                           if (with_cpu and ctx.rank == 0 and ctx.world == 1) else None)
+    if with_cpu and ctx.rank == 0 and ctx.world == 1:
+        out["cpu_baseline"] = burgers_cpu_baseline(sd_cpu, cond, args.cpu_budget * 0.5)
+    else:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_null_reason"] = "CPU legs run on rank 0 at N=1 only (or --no-cpu-baseline)"
     return out
 
 
@@ -501,7 +595,10 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
         ctx.log(t_start, f"train (exact backward, x6): {sec6 * 1e3:.1f} ms per optimizer step")
         del tr6
     out["cpu_baseline"] = None
+    out["cpu_baseline_null_reason"] = ("folded into the default line without its CPU leg (one oracle forward + autograd backward at B=1 is ~30 s); "
+                                       "`python bench.py --workload train` times it")
     if with_cpu and ctx.rank == 0 and ctx.world == 1:
+        out.pop("cpu_baseline_null_reason")
         from oracle import train_smoke as TS
         from oracle import unet3d as O
         cores = usable_cores()
@@ -519,8 +616,9 @@ def run_train(ctx, args, t_start, batch=16, with_cpu=True):
     return out
 
 
-def run_s128_leg(ctx, args, t_start, batch=8):
-    """BASELINE.json configs[4] shape (S128: 128 x 128 x 64 frames), batch 8 per GPU, micro-batch 4: the headline step at that extent."""
+def run_s128_leg(ctx, args, t_start, batch=64):
+    """BASELINE.json configs[4] (S128: 128 x 128 x 64 frames, prior-reweighted dual diffusion, batch 512 over 8 GPUs = 64 per GPU),
+    micro-batch 4: the headline step at that extent and at the config's per-GPU batch (r04 ran B = 8)."""
     from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
     gd, _ = build_models(ctx.device, 4, frames=64, size=128)      # micro-batch 4 (1: 361 ms per step, 2: 326, 4: 308)
     guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
@@ -540,8 +638,12 @@ def run_s128_leg(ctx, args, t_start, batch=8):
             "unit": "trajectories/s", "n_gpus": ctx.world, "steps": args.steps, "ms_per_step": sec * 1e3,
             "ms_per_step_min_rank": sec_min * 1e3, "world_size_seen_by_rccl": ctx.seen_world, "dtype": dtype_label(gd.model_joint.modes),
             "roofline_step": step_roofline(gd.model_joint.modes, batch * 14534.0e9, sec, f"{batch} x 14534 GFLOP (SURVEY.md 8d) per step / ms_per_step"),
-            "config": {"workload": f"S128 shape (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU, micro-batch 4",
-                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
+            "config": {"workload": f"S128 (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU (512 / 8), micro-batch 4",
+                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"},
+            "roofline": None, "roofline_null_reason": "per-class events are taken on the S64 headline only; roofline_step covers this leg",
+            "cpu_baseline": None,
+            "cpu_baseline_null_reason": "one S128 step of one trajectory is ~8x the S64 unit (14.5 TFLOP: about a minute on the host "
+                                        "cores); the S64 cpu_baseline of this line is the CPU figure of record (BASELINE.md 3 plans none for S128)"}
 
 
 def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
@@ -580,7 +682,10 @@ def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
             "config": {"workload": f"J128 (BASELINE.json configs[3]): 2D jellyfish full-obs {image_size}x{image_size} x {frames} "
                                    f"frames, joint+prior Unet3D reweighted + design gradient on libdpc, batch={batch} per GPU; "
                                    "per-step time = (20-step run - 4-step run) / 16 of the entry script's pipeline",
-                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"}}
+                       "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"},
+            "cpu_baseline": None,
+            "cpu_baseline_null_reason": "no CPU restatement of the J128 step is timed: one guided step of one trajectory (two 20 x 128 x 128 video "
+                                        "U-Nets + autograd through both surrogates) is minutes of host time; BASELINE.md 3 plans none"}
 
 
 def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
@@ -635,7 +740,10 @@ def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
            "sample_seconds": samp, "sample_seconds_min_rank": samp_min, "evaluate_seconds": evl, "wall_seconds": total,
            "trajectories_per_s_sampling": ctx.world * batch / samp, "trajectories_per_s_end_to_end": ctx.world * batch / total,
            "ms_per_step_measured": samp / steps * 1e3, "unit": "trajectories/s", "measured": "wall clock of one complete pass, not extrapolated",
-           "metric_row": {k: float(v.reshape(-1)[0]) for k, v in J.items()}}
+           "metric_row": {k: float(v.reshape(-1)[0]) for k, v in J.items()},
+           "cpu_baseline": None,
+           "cpu_baseline_null_reason": "a whole pass on the host cores would take hours (cpu_baseline of the headline: per-step rate x 1000); "
+                                       "the evaluator's share is timed in smoke_evaluator.cpu_baseline"}
     if ms_per_step is not None:
         ratio = (samp / steps * 1e3) / ms_per_step
         out["vs_headline_ms_per_step"] = ratio
@@ -648,8 +756,12 @@ def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
     return out
 
 
-def run_smoke_evaluator(ctx, B=64, T=256):
-    """Post-sampling PDE evaluator: B rollouts x T frames in one launch, as multi_evaluate consumes them."""
+def run_smoke_evaluator(ctx, B=64, T=256, with_cpu=True):
+    """Post-sampling PDE evaluator: B rollouts x T frames in one launch, as multi_evaluate consumes them.
+    cpu_baseline (evaluate_solver.py:205): the NumPy oracle of the same rollout -- bit-identical to the
+    reference's phi run -- on ONE process (the plan's "31 steps extrapolated to 255" is run in full: all 255 steps of one rollout) and
+    on `cores` processes, one rollout each (the reference's own parallelism: inference_2d_smoke.py:339-364 forks one process per
+    trajectory)."""
     import numpy as np
     from diffphycon_amd.dataset.apps import evaluate_solver as E
     rng = np.random.default_rng(0)
@@ -668,10 +780,27 @@ def run_smoke_evaluator(ctx, B=64, T=256):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     its = out[4].double()
-    return {"rollouts_per_s": B / dt, "seconds": dt, "batch": B, "frames": T, "mean_cg_iterations_per_frame": its.mean().item(),
-            "us_per_cg_iteration": dt * 1e6 / max(its.sum().item() / B, 1.0),
-            "note": "smoke PDE rollouts (phi advect + masked CG pressure solve, fp64, bit-exact vs the reference) of 64 "
-                    "sampled control sequences; end-to-end figure next to trajectories/s (SURVEY.md 8d)"}
+    res = {"rollouts_per_s": B / dt, "seconds": dt, "batch": B, "frames": T, "mean_cg_iterations_per_frame": its.mean().item(),
+           "us_per_cg_iteration": dt * 1e6 / max(its.sum().item() / B, 1.0),
+           "note": "smoke PDE rollouts (phi advect + masked CG pressure solve, fp64, bit-exact vs the reference) of 64 "
+                   "sampled control sequences; end-to-end figure next to trajectories/s (SURVEY.md 8d)"}
+    if with_cpu:
+        import multiprocessing as mp
+        cores = usable_cores()
+        one = _smoke_oracle_rollout((d0[0], c1[0], c2[0], T))
+        with mp.get_context("fork").Pool(cores) as pool:           # NumPy only in the workers; no GPU context is touched
+            t0 = time.perf_counter()
+            per = pool.map(_smoke_oracle_rollout, [(d0[i % B], c1[i % B], c2[i % B], T) for i in range(cores)])
+            wall = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": cores / wall, "unit": "rollouts/s", "cores": cores, "kind": "port",
+                               "value_one_process": 1.0 / one,
+                               "sample": f"NumPy oracle (bit-identical to the reference's phi rollout), {T} frames at 128^2: one process, one "
+                                         f"rollout: {one:.2f} s; {cores} processes, one rollout each: {wall:.2f} s wall "
+                                         f"(slowest worker {max(per):.2f} s)"}
+    else:
+        res["cpu_baseline"] = None
+        res["cpu_baseline_null_reason"] = "--no-cpu-baseline"
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ launch plumbing
@@ -888,8 +1017,10 @@ def main():
             if rank == 0:
                 out["burgers"] = bo
             if rank == 0 and world == 1:
-                out["smoke_evaluator"] = run_smoke_evaluator(ctx)
+                out["smoke_evaluator"] = run_smoke_evaluator(ctx, with_cpu=not args.no_cpu_baseline)
                 ctx.log(t_start, "evaluator leg done")
+                out["burgers_fd"] = burgers_fd_leg(ctx, not args.no_cpu_baseline, args.cpu_budget)
+                ctx.log(t_start, "Burgers FD leg done")
             # the other BASELINE configs and the training step, short legs folded into the same line
             del gd
             torch.cuda.empty_cache()

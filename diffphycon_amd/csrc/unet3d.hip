@@ -588,6 +588,7 @@ struct Runner {
             resnet(p + ".0", x, sk, xc, dout, di, U, true, Hl, Wl);          // cat((x, h.pop()), dim=1) is virtual
             tap(p + ".0", U, di, Hl, Wl);
             resnet(p + ".1", U, nullptr, di, 0, di, U, true, Hl, Wl);
+            tap(p + ".1", U, di, Hl, Wl);
             spatial_linear(p + ".2", U, di, Hl, Wl);
             tap(p + ".2", U, di, Hl, Wl);
             attention(p + ".3", U, di, Hl, Wl, true);

@@ -246,6 +246,7 @@ def unet3d_forward(sd, cfg, x, time, taps=None):
         x = resnet_block(sd, p + ".0", x, t, g)
         tap(p + ".0", x)
         x = resnet_block(sd, p + ".1", x, t, g)
+        tap(p + ".1", x)
         x = spatial_linear_attention(sd, p + ".2.fn", x, heads)
         tap(p + ".2", x)
         x = temporal_attention(sd, p + ".3.fn", x, heads, bias)

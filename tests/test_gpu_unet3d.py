@@ -25,6 +25,28 @@ TAP_TOL = 1e-5            # measured worst tap 3.2e-6
 OUT_TOL = 1e-5            # measured worst output 3.1e-6
 
 
+def _compare_taps(m, refs, dev, tol, expect):
+    """Every named reference tensor against the HIP forward's debug tap of that name -- NO silent skips (three
+    helpers used to `continue` on a tap they could not fetch): a tap the library does not record is a failure, and the number of
+    compared taps is asserted against what the caller expects for its net."""
+    bad, checked = [], 0
+    for name, ref in refs:
+        got = m.get_tap(name, tuple(ref.shape), dev).cpu()          # raises (= fails the test) if the library did not record it
+        err = note_error(name, ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item())
+        checked += 1
+        if err > tol:
+            bad.append((name, err))
+    assert not bad, bad
+    assert checked >= expect, (checked, expect)
+    return checked
+
+
+def _n_taps(n_levels):
+    """Taps oracle.unet3d_forward records for a net of n_levels resolution levels: init_conv, init_temporal_attn, time_mlp; per down
+    level .0-.3 (+ .4 except the last); 4 mid taps; per up level .0-.3 (+ .4 except the last); final_conv.0."""
+    return 3 + (4 * n_levels + n_levels - 1) + 4 + (4 * n_levels + n_levels - 1) + 1
+
+
 def _model_from_golden(g, prefix, dev, channels, dim, mults, micro_batch=0, arithmetic=None):
     from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     m = Unet3D_with_Conv3D(dim=dim, dim_mults=mults, channels=channels, micro_batch=micro_batch, arithmetic=arithmetic)
@@ -44,16 +66,9 @@ def test_unet3d_matches_reference_fixture(tag, arithmetic, dev):
     x, t = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["t"]).to(dev)
     m.debug_taps(True)
     y = m(x, t)
-    bad = []
-    for k in g.files:
-        if not k.startswith("tap:"):
-            continue
-        ref = torch.from_numpy(g[k])
-        got = m.get_tap(k[4:], tuple(ref.shape), dev).cpu()
-        err = note_error(k, ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item())
-        if err > TAP_TOL:
-            bad.append((k, err))
-    assert not bad, bad
+    refs = [(k[4:], torch.from_numpy(g[k])) for k in g.files if k.startswith("tap:")]
+    # tools/gen_golden.py records 17 taps of the reference for the joint / prior nets, 2 (a block input / output pair) for the wide one
+    _compare_taps(m, refs, dev, TAP_TOL, expect=2 if tag == "wide" else 17)
     ref = torch.from_numpy(g["y"])
     err = note_error("y", ((y.cpu() - ref).abs().max() / ref.abs().max()).item())
     assert err < OUT_TOL, err
@@ -87,16 +102,8 @@ def test_unet3d_full_width_vs_oracle(channels, seed, dev):
     m = m.to(dev)
     m.debug_taps(True)
     y = m(x.to(dev), t.to(dev)).cpu()
-    bad = []
-    for name, r in taps.items():
-        try:
-            got = m.get_tap(name, tuple(r.shape), dev).cpu()
-        except RuntimeError:
-            continue
-        err = note_error(name, ((got - r).abs().max() / (r.abs().max() + 1e-12)).item())
-        if err > TAP_TOL:
-            bad.append((name, err))
-    assert not bad, bad
+    assert len(taps) == _n_taps(3)
+    _compare_taps(m, list(taps.items()), dev, TAP_TOL, expect=_n_taps(3))
     err = note_error("y", ((y - ref).abs().max() / ref.abs().max()).item())
     assert err < OUT_TOL, err
 
@@ -119,30 +126,26 @@ def _oracle_parity(dev, cfg_kw, seed, shape, t, tol=None, arithmetic=None):
     m.debug_taps(True)
     y = m(x.to(dev), tt.to(dev)).cpu()
     assert y.shape == ref.shape
-    bad = []
-    for name, r in taps.items():
-        try:
-            got = m.get_tap(name, tuple(r.shape), dev).cpu()
-        except RuntimeError:
-            continue
-        err = note_error(name, ((got - r).abs().max() / (r.abs().max() + 1e-12)).item())
-        if err > tol:
-            bad.append((name, err))
-    assert not bad, bad
+    n_levels = len(cfg_kw["dim_mults"])
+    assert len(taps) == _n_taps(n_levels)
+    _compare_taps(m, list(taps.items()), dev, tol, expect=_n_taps(n_levels))
     err = note_error("y", ((y - ref).abs().max() / ref.abs().max()).item())
     assert err < tol, err
     return m
 
 
-@pytest.mark.parametrize("case", ["s64_joint", "s64_prior", "s128", "j128_state", "j128_theta"])
+@pytest.mark.parametrize("case", ["s64_joint", "s64_prior", "s128", "s128_prior", "j128_state", "j128_theta"])
 def test_full_extent_vs_oracle(case, dev):
     """HIP forward (default mode: f16x3, Winograd 3x3x3 convs) vs oracle.unet3d_forward at the FULL per-trajectory extent of S64 (32 x 64 x
     64, joint and prior nets), S128 (64 x 128 x 128) and J128 (20 x 128 x 128, 7 -> 4 and 7 -> 1), B = 1: the shapes where every level
     takes conv3w, the persistent loops walk many tiles per workgroup and the XCD-aware tile decode sees the production tile counts
     (...conv3d.py:486-552).  A deterministic, batch-independent full-size bug -- which the invariance tests cannot see -- fails here.
     The oracle side (minutes of host time per case) is a committed fixture: tools/gen_golden_r04.py recorded, for every tap and the
-    output, the tensor's shape, max |value| and 4096 values at seeded positions (tests/golden/full_extent_<case>.npz; the s64_prior file
-    is re-derived from the oracle by tests/test_oracle_unet3d.py).  Compared at TAP_TOL / OUT_TOL of the tensor's range."""
+    output, the tensor's shape, max |value| and its values at 4096 seeded random positions PLUS (r05) a deterministic set of whole lines
+    along the frame / row / column axes through first and last points of the kernels' 4 x 8 x 8 tiles -- every tile and every tile seam
+    of every tensor is touched (`gen_golden_r04.edge_index`; tests/golden/full_extent_<case>.npz; the s64_prior file is re-derived from
+    the oracle by tests/test_oracle_unet3d.py).  s128_prior (r05) = the 2-channel prior net at the S128 extent.  Every recorded tap must
+    be fetched (no skips); compared at TAP_TOL / OUT_TOL of the tensor's range."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -163,11 +166,8 @@ def test_full_extent_vs_oracle(case, dev):
             got = y
             assert tuple(y.shape) == shape
         else:
-            try:
-                got = m.get_tap(name, shape, dev)
-            except RuntimeError:
-                continue
-        idx = torch.from_numpy(G.sample_index(seed, k, got.numel())).to(dev)
+            got = m.get_tap(name, shape, dev)                         # a tap the library does not record fails the test
+        idx = torch.from_numpy(G.sample_index(seed, k, got.numel(), shape, 2 if name == "y" else 1)).to(dev)
         vals = got.reshape(-1)[idx].cpu()
         ref = torch.from_numpy(g[f"values:{name}"])
         err = note_error(name, ((vals - ref).abs().max() / float(g[f"absmax:{name}"])).item())
@@ -175,7 +175,7 @@ def test_full_extent_vs_oracle(case, dev):
         if err > (OUT_TOL if name == "y" else TAP_TOL):
             bad.append((name, err))
     assert not bad, bad
-    assert checked >= 30, checked
+    assert checked == len(g["names"]) == _n_taps(3) + 1, (checked, len(g["names"]))
 
 
 def test_s128_sequence_length_64_frames_vs_oracle(dev):
@@ -349,16 +349,8 @@ def test_unet3d_full_width_32_frames_vs_oracle(dev):
     m = m.to(dev)
     m.debug_taps(True)
     y = m(x.to(dev), t.to(dev)).cpu()
-    bad = []
-    for name, r in taps.items():
-        try:
-            got = m.get_tap(name, tuple(r.shape), dev).cpu()
-        except RuntimeError:
-            continue
-        err = ((got - r).abs().max() / (r.abs().max() + 1e-12)).item()
-        if err > 2e-5:
-            bad.append((name, err))
-    assert not bad, bad
+    assert len(taps) == _n_taps(3)
+    _compare_taps(m, list(taps.items()), dev, 2e-5, expect=_n_taps(3))
     err = ((y - ref).abs().max() / ref.abs().max()).item()
     assert err < 2e-5, err
 

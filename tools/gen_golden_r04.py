@@ -3,12 +3,15 @@ to the imported reference by tests/test_oracle_*.py) on seeded inputs whose eval
 suite does not re-run them on every box:
 
   full_extent_<case>.npz : oracle.unet3d_forward at the FULL extent of a BASELINE config (tests/test_gpu_unet3d.py: _FULL_EXTENT) -- for
-                           every tap and the output: the tensor's shape, its max |value| and NSAMP values at positions drawn by
-                           numpy.random.RandomState(seed of the case + index of the tap) (`sample_index` below; the test draws the same);
+                           every tap and the output: the tensor's shape, its max |value| and its values at `sample_index`'s positions
+                           (the test draws the same): NSAMP positions from numpy.random.RandomState(seed of the case + index of
+                           the tap) and, since r05, a DETERMINISTIC set on the boundaries the kernels tile by (`edge_index`: whole
+                           lines along the frame, row and column axes through first / last points of the 4 x 8 x 8 output tiles,
+                           so every tile of the tensor and every seam between two tiles -- along each axis -- is touched);
   drift_chain.npz        : the final state of the 100-step free-running guided DDPM chain of
                            test_full_width_100_step_chain_f16x3_drift_vs_exact_and_oracle on the oracle.
 
-    python tools/gen_golden_r04.py [case ...]        (no argument: everything; ~6 minutes on 8 cores, ~12 GB of host memory)
+    python tools/gen_golden_r04.py [case ...]        (no argument: everything; ~10 minutes on 8 cores, ~12 GB of host memory)
 
 tests/test_oracle_unet3d.py re-computes the s64_prior case and the first steps of the chain on the CPU and checks the files."""
 import os
@@ -28,12 +31,44 @@ FULL_EXTENT = {
     "s128": (dict(dim=64, dim_mults=(1, 2, 4), channels=6), 43, (1, 64, 6, 128, 128), [250]),
     "j128_state": (dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=4), 44, (1, 20, 7, 128, 128), [999]),
     "j128_theta": (dict(dim=64, dim_mults=(1, 2, 4), channels=7, out_dim=1), 45, (1, 20, 7, 128, 128), [3]),
+    # r05: the 2-channel prior net of the prior-reweighted S128 config (inference_2d_smoke.py:48-52, 80-84) at ITS extent
+    "s128_prior": (dict(dim=64, dim_mults=(1, 2, 4), channels=2), 46, (1, 64, 2, 128, 128), [512]),
 }
 
 
-def sample_index(seed, k, numel):
-    """Positions (flat, C-order) of the samples of the k-th recorded tensor of a case."""
-    return np.random.RandomState(1000 * seed + k).randint(0, numel, size=min(NSAMP, numel)).astype(np.int64)
+def edge_index(shape, channels_axis):
+    """Deterministic positions (flat, C-order) of a [1, C, F, H, W] tap (channels_axis 1) or the [1, F, C, H, W] output (2):
+    whole LINES through the tensor along each of the frame / row / column axes, anchored at points that are first or last in a
+    4 x 8 x 8 output tile of the convolution kernels (f in {0, 3, 4, F-1}, h, w in {0, 7, 8, H-1}; plus the centre seam), for
+    three channels (first, middle, last: the 64- and 128-column blocks' ends).  A line crosses every tile along its axis and both
+    sides of every tile seam, whatever the workgroup -> tile (XCD chunk) order is; a wrong tile narrower than the random sample's
+    reach (~2 k elements at 4096 draws from 8.4 M) cannot hide from all three families."""
+    if len(shape) != 5:
+        return np.zeros(0, dtype=np.int64)
+    if channels_axis == 1:
+        _, C, F_, H, W = shape
+    else:
+        _, F_, C, H, W = shape
+    cs = sorted({0, C // 2, C - 1})
+    fa = sorted({0, min(3, F_ - 1), min(4, F_ - 1), F_ - 1})
+    ha = sorted({0, min(7, H - 1), min(8, H - 1), H // 2 - 1 if H > 1 else 0, H - 1})
+    wa = sorted({0, min(7, W - 1), min(8, W - 1), W // 2 if W > 1 else 0, W - 1})
+    pts = []
+    for c in cs:
+        pts += [(c, f, h, w) for f in range(F_) for h, w in zip(ha, wa)]                  # lines along the frame axis
+        pts += [(c, f, h, w) for h in range(H) for f in fa for w in wa]                   # lines along rows
+        pts += [(c, f, h, w) for w in range(W) for f in fa for h in ha]                   # lines along columns
+    a = np.array(sorted(set(pts)), dtype=np.int64)
+    c, f, h, w = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    return (((c * F_ + f) * H + h) * W + w) if channels_axis == 1 else (((f * C + c) * H + h) * W + w)
+
+
+def sample_index(seed, k, numel, shape=None, channels_axis=1):
+    """Positions (flat, C-order) of the samples of the k-th recorded tensor of a case: NSAMP random draws followed by `edge_index`."""
+    rnd = np.random.RandomState(1000 * seed + k).randint(0, numel, size=min(NSAMP, numel)).astype(np.int64)
+    if shape is None:
+        return rnd
+    return np.concatenate([rnd, edge_index(tuple(int(v) for v in shape), channels_axis)])
 
 
 def full_extent_inputs(case):
@@ -55,7 +90,8 @@ def full_extent_record(case):
         flat = r.contiguous().reshape(-1)
         out[f"shape:{name}"] = np.array(r.shape, dtype=np.int64)
         out[f"absmax:{name}"] = np.float32(flat.abs().max().item())
-        out[f"values:{name}"] = flat[torch.from_numpy(sample_index(seed, k, flat.numel()))].numpy().astype(np.float32)
+        idx = sample_index(seed, k, flat.numel(), tuple(r.shape), 2 if name == "y" else 1)
+        out[f"values:{name}"] = flat[torch.from_numpy(idx)].numpy().astype(np.float32)
     return out
 
 
