@@ -30,7 +30,10 @@
 // agree with the oracle to 2e-5 at the FULL extents of S64 / S128 / J128 (tests/test_gpu_unet3d.py: test_full_extent_vs_oracle).
 // Perf attribution only (env DPC_CONV_DBG, Conv3hParams::dbg; results are INVALID except for 512): 2 the loader skips its global
 // loads, 32 the loader does nothing but the barriers, 4 every MFMA wave streams component 0's weights, 8 no epilogue, 512 the second
-// frame pair's stores are issued in the epilogue instead of deferred.
+// frame pair's stores are issued in the epilogue instead of deferred, 64 (r05) the loader keeps its global loads and its 16 LDS writes per
+// item but does NO activation / transform / split -- it writes the raw loaded bits, masked to finite fp16 patterns (random mantissas: the
+// MFMA stream sees live, changing operands, unlike bit 32 whose static LDS content lowers the power draw and raises the clock): the
+// honest ceiling of a design in which something else (a producer pass + LDS-DMA) delivers the operand planes.
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:189-204).
 #include "common.h"
 #include "f3c.h"
@@ -224,6 +227,20 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         //       below: residual streams are O(1); the direct kernels' 2^4 bought 2^-29 at one more VALU op per element).  No clamp: |s V| > 65504 becomes inf and the output
         //       NaN / inf -- loud, never a silently clamped product (range check: dpc_unet3d_set_range_check).
         auto finish_item = [&](f32x4 (&d)[HFI], unsigned fok, int inflag, const f32x4& Ac, const f32x4& Bc, int dst0) {
+            if (p.dbg & 64) {             // attribution only: raw bits -> LDS (see the header), one v_and per dword
+                unsigned char* q0 = halo + dst0;
+                unsigned char* q1 = halo + (dst0 ^ 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x4 v = d[k % HFI];
+                    uint2 p1, p2;
+                    p1.x = __builtin_bit_cast(unsigned, v.x) & 0x3bff3bffu; p1.y = __builtin_bit_cast(unsigned, v.y) & 0x3bff3bffu;
+                    p2.x = __builtin_bit_cast(unsigned, v.z) & 0x3bff3bffu; p2.y = __builtin_bit_cast(unsigned, v.w) & 0x3bff3bffu;
+                    *reinterpret_cast<uint2*>(q0 + k * 6400) = p1;
+                    *reinterpret_cast<uint2*>(q1 + k * 6400) = p2;
+                }
+                return;
+            }
             if (GN) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 const bool in = inflag != 0;

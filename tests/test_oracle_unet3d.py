@@ -85,3 +85,23 @@ def test_r04_fixtures_are_what_the_oracle_computes():
     after3 = G.drift_chain_oracle(3).numpy()
     assert np.abs(after3 - d["after3"]).max() <= 2e-6 * np.abs(d["after3"]).max()
     assert d["final"].shape == d["after3"].shape and np.isfinite(d["final"]).all()
+
+
+def test_s128_prior_fixture_is_what_the_oracle_computes():
+    """r05: tests/golden/full_extent_s128_prior.npz (the 2-channel prior net at the S128 extent, 64 x 128 x 128: VERDICT r04 missing #3)
+    re-derived from the oracle: shapes, maxima, the 4096 random samples AND the deterministic tile-edge lines of every tap
+    (gen_golden_r04.edge_index).  ~1.5 minutes on 8 cores."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_golden_r04 as G
+    g = load_golden("full_extent_s128_prior")
+    rec = G.full_extent_record("s128_prior")
+    assert list(rec["names"]) == list(g["names"]) and len(rec["names"]) == 37
+    for k, name in enumerate(g["names"]):
+        assert np.array_equal(rec[f"shape:{name}"], g[f"shape:{name}"])
+        shape = tuple(int(v) for v in g[f"shape:{name}"])
+        n_edge = len(G.edge_index(shape, 2 if name == "y" else 1))
+        assert len(g[f"values:{name}"]) == min(G.NSAMP, int(np.prod(shape))) + n_edge and (n_edge > 4000 or len(shape) != 5)
+        scale = float(g[f"absmax:{name}"])
+        assert np.abs(rec[f"values:{name}"] - g[f"values:{name}"]).max() <= 2e-6 * scale, name
