@@ -688,15 +688,15 @@ def run_j128(ctx, args, t_start, batch=16, image_size=128, frames=20):
                                         "U-Nets + autograd through both surrogates) is minutes of host time; BASELINE.md 3 plans none"}
 
 
-def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
+def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH, batches=1, overlap=True):
     """ONE real pass of the entry script's pipeline (inference/inference_2d_smoke.py main() on the synthetic test split, the
     reference's :179-197 + :317-427): `GaussianDiffusion.sample()` of `batch` trajectories per GPU -- 1000 guided DDPM steps
     (ddim=False) or the script's CLI default DDIM-100 (ddim=True, :511-517) -- then the PDE evaluator (solver_batch) + multi_evaluate,
     metric rows gathered over the ranks as the script does.  Nothing is extrapolated: seconds are wall seconds of that pass."""
     sys.path.insert(0, os.path.join(ROOT, "inference"))
     import inference_2d_smoke as S
-    a = S.build_parser().parse_args(["--synthetic", "True", "--batch_size", str(batch), "--n_test", str(batch * ctx.world),
-                                     "--using_ddim", str(bool(ddim)), "--ddim_sampling_steps", "100",
+    a = S.build_parser().parse_args(["--synthetic", "True", "--batch_size", str(batch), "--n_test", str(batch * ctx.world * batches),
+                                     "--using_ddim", str(bool(ddim)), "--ddim_sampling_steps", "100", "--overlap_evaluator", str(bool(overlap)),
                                      "--inference_result_path", "/tmp/dpc_bench_e2e"])
     a.device, a.rank, a.world_size = ctx.device, ctx.rank, ctx.world
     a.inference_result_subpath = os.path.join(a.inference_result_path, f"{'ddim' if ddim else 'ddpm'}_{os.getpid()}")
@@ -713,6 +713,8 @@ def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
         ppl.multi_evaluate(ppl.run_model(st0), st0)
         diffusion[0].sampling_timesteps, diffusion[0].is_ddim_sampling = tiny
         spent = {"sample": 0.0, "evaluate": 0.0}
+        sample_events = []
+        overlapped = bool(overlap) and batches > 1
 
         def timed(name, fn):
             def wrapped(*x, **kw):
@@ -723,29 +725,52 @@ def run_e2e(ctx, args, t_start, ddim, ms_per_step=None, batch=LOCAL_BATCH):
                 spent[name] += time.perf_counter() - t0
                 return out
             return wrapped
-        ppl.run_model = timed("sample", ppl.run_model)
-        ppl.multi_evaluate = timed("evaluate", ppl.multi_evaluate)
+
+        def timed_on_stream(fn):
+            # overlapped schedule: a device-wide synchronize would serialise the side stream's rollouts with the sampling; the sampling
+            # time is taken with events on the sampling stream instead (it INCLUDES what the co-resident rollouts cost the sampling)
+            def wrapped(*x, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*x, **kw)
+                e1.record()
+                sample_events.append((e0, e1))
+                return out
+            return wrapped
+        if overlapped:
+            ppl.run_model = timed_on_stream(ppl.run_model)
+        else:
+            ppl.run_model = timed("sample", ppl.run_model)
+            ppl.multi_evaluate = timed("evaluate", ppl.multi_evaluate)
         ctx.sync()
         t0 = time.perf_counter()
         J = ppl.run(loader)
         ctx.sync()
         total = time.perf_counter() - t0
+        if overlapped:
+            spent["sample"] = sum(e0.elapsed_time(e1) for e0, e1 in sample_events) * 1e-3
+            spent["evaluate"] = max(total - spent["sample"], 0.0)         # what the evaluator still adds to the wall clock
     total, _ = ctx.reduce(total)
     samp, samp_min = ctx.reduce(spent["sample"])
     evl, _ = ctx.reduce(spent["evaluate"])
     steps = 100 if ddim else STEPS_PER_TRAJECTORY
     out = {"pipeline": "inference/inference_2d_smoke.py main(): sample() + solver_batch + multi_evaluate, synthetic test split, "
                        f"random-init denoisers, {'DDIM-100, eta 1 (the CLI default)' if ddim else '1000-step guided DDPM'}",
-           "batch_per_gpu": batch, "n_gpus": ctx.world, "world_size_seen_by_rccl": ctx.seen_world, "sampling_steps": steps,
+           "batch_per_gpu": batch, "batches": batches, "n_gpus": ctx.world, "world_size_seen_by_rccl": ctx.seen_world, "sampling_steps": steps,
+           "schedule": ("evaluator of batch i on a side stream under the sampling of batch i + 1 (InferencePipeline.run, r05); sample_seconds = "
+                        "event time on the sampling stream, evaluate_seconds = wall - sample_seconds = what the evaluator still adds"
+                        if overlapped else "serial: sample, evaluate, next batch (the reference's loop, inference_2d_smoke.py:259-271)"),
            "sample_seconds": samp, "sample_seconds_min_rank": samp_min, "evaluate_seconds": evl, "wall_seconds": total,
-           "trajectories_per_s_sampling": ctx.world * batch / samp, "trajectories_per_s_end_to_end": ctx.world * batch / total,
-           "ms_per_step_measured": samp / steps * 1e3, "unit": "trajectories/s", "measured": "wall clock of one complete pass, not extrapolated",
+           "trajectories_per_s_sampling": ctx.world * batch * batches / samp,
+           "trajectories_per_s_end_to_end": ctx.world * batch * batches / total,
+           "end_to_end_over_sampling_only": samp / total,
+           "ms_per_step_measured": samp / (steps * batches) * 1e3, "unit": "trajectories/s", "measured": "wall clock of one complete pass, not extrapolated",
            "metric_row": {k: float(v.reshape(-1)[0]) for k, v in J.items()},
            "cpu_baseline": None,
            "cpu_baseline_null_reason": "a whole pass on the host cores would take hours (cpu_baseline of the headline: per-step rate x 1000); "
                                        "the evaluator's share is timed in smoke_evaluator.cpu_baseline"}
     if ms_per_step is not None:
-        ratio = (samp / steps * 1e3) / ms_per_step
+        ratio = (samp / (steps * batches) * 1e3) / ms_per_step
         out["vs_headline_ms_per_step"] = ratio
         out["agrees_with_headline_within_2pct"] = bool(abs(ratio - 1.0) <= 0.02)
         if not out["agrees_with_headline_within_2pct"]:
@@ -914,7 +939,13 @@ def main():
         return
 
     if args.workload in ("e2e", "ddim100"):
-        out = run_e2e(ctx, args, t_start, ddim=args.workload == "ddim100", batch=args.batch or LOCAL_BATCH)
+        nb = 2 if args.workload == "ddim100" else 1
+        out = run_e2e(ctx, args, t_start, ddim=args.workload == "ddim100", batch=args.batch or LOCAL_BATCH, batches=nb)
+        if nb > 1:
+            ser = run_e2e(ctx, args, t_start, ddim=True, batch=args.batch or LOCAL_BATCH, batches=nb, overlap=False)
+            out["serial_schedule"] = {k: ser[k] for k in ("schedule", "sample_seconds", "evaluate_seconds", "wall_seconds",
+                                                            "trajectories_per_s_sampling", "trajectories_per_s_end_to_end", "metric_row")}
+            out["metric_rows_equal_serial"] = out["metric_row"] == ser["metric_row"]
         if rank == 0:
             out.update({"launcher": launcher, "roofline": None, "cpu_baseline": None})
             print(json.dumps(out), flush=True)
@@ -1032,7 +1063,7 @@ def main():
             legs["train"] = run_train(ctx, extra, t_start, with_cpu=False)
             # the CLI default (DDIM-100) and ONE real 1000-step trajectory batch through the entry script's pipeline, evaluator included
             if not args.no_e2e:
-                legs["ddim100"] = run_e2e(ctx, args, t_start, ddim=True)
+                legs["ddim100"] = run_e2e(ctx, args, t_start, ddim=True, batches=2)        # 2 batches: the evaluator overlap is in the schedule
                 legs["e2e"] = run_e2e(ctx, args, t_start, ddim=False, ms_per_step=sec * 1e3)
             if rank == 0:
                 out.update(legs)

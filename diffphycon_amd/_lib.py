@@ -87,6 +87,7 @@ _P, _I, _L, _Z, _D, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_doubl
 _SIGNATURES = {
     "dpc_version": (C.c_int, []),
     "dpc_build_info": (C.c_char_p, []),
+    "dpc_set_cu_budget": (C.c_int, [C.c_int]),
     "dpc_last_error": (C.c_char_p, []),
     "dpc_set_mode": (C.c_int, [C.c_char_p, C.c_char_p]),
     "dpc_get_mode": (C.c_char_p, [C.c_char_p]),

@@ -64,14 +64,15 @@ def scan_packed_fp32(path):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def _stamp_object(n_packed, n_objs, flags):
+def _stamp_object(n_packed, n_objs, flags, outdir=None):
     """lib/build_stamp.o: `dpc_build_info()` (include/dpc.h) -- what the build MEASURED on the linked device code, not what it was asked
     to do: the count of packed fp32 instructions found by scan_packed_fp32 and the flags of the compile."""
-    src = os.path.join(LIBDIR, "build_stamp.c")
+    outdir = outdir or LIBDIR
+    src = os.path.join(outdir, "build_stamp.c")
     text = f"packed_fp32_insts={n_packed};code_objects={n_objs};flags={' '.join(flags)}".replace("\\", "/").replace('"', "'")
     with open(src, "w") as f:
         f.write('/* generated by diffphycon_amd/build.py */\nconst char* dpc_build_info(void) { return "' + text + '"; }\n')
-    obj = os.path.join(LIBDIR, "build_stamp.o")
+    obj = os.path.join(outdir, "build_stamp.o")
     subprocess.check_call([os.environ.get("CC", "gcc"), "-O1", "-fPIC", "-c", src, "-o", obj])
     return obj
 

@@ -1,4 +1,5 @@
 // extern "C" surface of libdpc (see include/dpc.h): error plumbing and the operator-level entry points.
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -104,6 +105,14 @@ int stream_scratch(int slot, hipStream_t s, size_t bytes, float** out) {
     *out = static_cast<float*>(e.p);
     return DPC_OK;
 }
+// CU budget of the persistent kernels (dpc_set_cu_budget): the grids of conv3w / conv3f3c / tattn3 are "one workgroup per CU"; while a
+// long-running kernel of ANOTHER stream occupies some CUs (the smoke evaluator: one 129 KB-LDS workgroup per rollout), a full-size
+// grid would leave workgroups waiting for a CU and their statically assigned tiles would run as a second round.
+static std::atomic<int> g_cu_budget{0};
+int cu_budget(int ncu) {
+    const int b = g_cu_budget.load(std::memory_order_relaxed);
+    return (b > 0 && b < ncu) ? std::max(8, b / 8 * 8) : ncu;
+}
 int conv_mode_default() { return modes_current().conv; }
 int igemm_mode_default() { return modes_current().igemm; }
 }  // namespace dpc
@@ -112,7 +121,12 @@ using namespace dpc;
 
 extern "C" {
 
-int dpc_version(void) { return 101; }
+int dpc_version(void) { return 102; }
+int dpc_set_cu_budget(int cus) {
+    DPC_REQUIRE(cus >= 0, "set_cu_budget: negative");
+    g_cu_budget.store(cus, std::memory_order_relaxed);
+    return DPC_OK;
+}
 const char* dpc_last_error(void) { return g_err.c_str(); }
 
 int dpc_set_mode(const char* family, const char* mode) {

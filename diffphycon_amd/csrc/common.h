@@ -127,6 +127,7 @@ struct OverflowScope {
 // cannot change which kernels run (the arithmetic modes DPC_*_MODE are the documented, per-handle-captured setting and are not
 // gated).  Switches that make a kernel skip work (DPC_CONV_DBG) exist only in builds with -DDPC_ENABLE_CONV_DBG.
 int debug_switch(const char* name, int dflt);
+int cu_budget(int ncu);           // api.hip: min(ncu, the value of dpc_set_cu_budget rounded down to a multiple of 8)
 // library-internal scratch buffer of at least `bytes` for (slot, current device, stream) -- api.hip; slots:
 enum { SCRATCH_SMALL_ACT = 0, SCRATCH_SPLITK = 1 };
 int stream_scratch(int slot, hipStream_t s, size_t bytes, float** out);

@@ -397,7 +397,7 @@ int launch_conv3f3c(const Conv3hParams& p, hipStream_t s) {
     }
     Conv3hParams pd = p;
     pd.total_wg = (int)nwg;
-    const unsigned grid = (unsigned)std::min<long long>(nwg, ncu);
+    const unsigned grid = (unsigned)std::min<long long>(nwg, cu_budget(ncu));
     if (p.kd == 1) {
         if (wide) hipLaunchKernelGGL((conv3f3c_kernel<128, 1>), dim3(grid), dim3(512), 2 * HBS, s, pd);
         else hipLaunchKernelGGL((conv3f3c_kernel<64, 1>), dim3(grid), dim3(512), 2 * HBS, s, pd);

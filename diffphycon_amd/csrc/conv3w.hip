@@ -634,7 +634,7 @@ int launch_conv3w(const Conv3hParams& p, hipStream_t s) {
     }
     Conv3hParams pd = p;
     pd.total_wg = (int)nwg;
-    const unsigned grid = (unsigned)std::min<long long>(nwg, ncu);
+    const unsigned grid = (unsigned)std::min<long long>(nwg, cu_budget(ncu));
     const bool wide = p.Npad % 128 == 0 && p.N > 64;       // profile class only (launch_conv3f3's ProfScope uses the same rule)
     if (p.in_coef) {
         if (wide) hipLaunchKernelGGL((conv3w_kernel<true, 128>), dim3(grid), dim3(512), 2 * HBS, s, pd);

@@ -13,9 +13,31 @@
 //    (<= 1): 2^10; weights: 2^12; every accumulator is rescaled exactly where it is consumed.
 #include "f16x3.h"
 
+// r05 experiment: the two K = 32 contractions of a head on the EXACT fp32 matrix instruction instead of f16x3.
+// A 32 x 32 projection accumulator is already an operand of v_mfma_f32_32x32x2_f32: register r of lane (l31, hh) holds element
+// (l31, k = rowmap3(r, hh)), the same k in the two accumulators that are contracted, so S^T = sum_r mfma(kT[r], qT[r]) and
+// O^T = sum_r mfma(vv[r], P[r]) need NO operand split (32 of a head's 80 split elements per lane each) -- for 16 64-cycle matrix
+// instructions instead of 6 32-cycle ones.  Compile-time switches for the interleaved A/B (profiles/r05_*attn*): 0 = f16x3 (r04).
+#ifndef DPC_TATTN_QK_F32
+#define DPC_TATTN_QK_F32 0
+#endif
+#ifndef DPC_TATTN_PV_F32
+#define DPC_TATTN_PV_F32 0
+#endif
+
 namespace dpc {
 
 using namespace h3;
+
+// acc += sum_r A[r] (x) B[r]: 16 exact fp32 products per lane pair on v_mfma_f32_32x32x2_f32 (lane (l31, hh): A[row l31][k = hh])
+__device__ __forceinline__ void mfma_f32_k32(f32x16& acc, const f32x16& a, const f32x16& b) {
+#ifdef DPC_DBG_NO_MFMA
+    asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
+    return;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+}
 
 // C = 64: all four heads resident, one launch.  C = 128: the weights of two heads (128 KB) fit, so the block runs as two
 // launches over head pairs: pass 1 (heads 0, 1) writes x + its partial to_out sum to a workspace, pass 2 (heads 2, 3) adds its own sum.
@@ -250,7 +272,15 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             f16x8 qs[2][2];
-            {
+            if constexpr (DPC_TATTN_QK_F32 != 0) {
+                // raw accumulators as operands: st = (true k . q) / (PROJ_DESCALE^2): the scale joins the softmax multiplier below
+                mfma_f32_k32(st, kT, qT);
+                asm volatile("" : "+v"(st) : "v"(kT), "v"(qT));       // (operand registers stay allocated behind the last MFMA: 6.2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) qs[i][pl] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            } else {
                 f16x8 kk[2][2];
                 split_acc_h<true>(qT, qscale * (PROJ_DESCALE * SQK), qs);
                 split_acc_h<true>(kT, PROJ_DESCALE * SQK, kk);
@@ -266,7 +296,9 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasL + (hd * 32 * TS + 8 * jj) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float sv = __builtin_fmaf(st[4 * jj + e], LOG2E / (SQK * SQK), b4[e]);
+                    constexpr float SMUL = DPC_TATTN_QK_F32 != 0 ? LOG2E * 0.17677669529663687f * (PROJ_DESCALE * PROJ_DESCALE)
+                                                                 : LOG2E / (SQK * SQK);
+                    float sv = __builtin_fmaf(st[4 * jj + e], SMUL, b4[e]);
                     if (!FULL && 8 * jj + 4 * hh + e >= F) sv = -INFINITY;
                     st[4 * jj + e] = sv;
                     m = fmaxf(m, sv);
@@ -286,7 +318,15 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
 #pragma unroll
             for (int r = 0; r < 16; ++r) oT[r] = 0.f;
             f16x8 ps[2][2];
-            {
+            if constexpr (DPC_TATTN_PV_F32 != 0) {
+                // oT = (true V^T P) SP / PROJ_DESCALE: folded into the multiplier of the O split below
+                mfma_f32_k32(oT, vv, st);
+                asm volatile("" : "+v"(oT) : "v"(vv), "v"(st));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) ps[i][pl] = qs[i][pl];
+            } else {
                 f16x8 vs[2][2];
                 split_acc_h<true>(vv, PROJ_DESCALE * SV, vs);
                 split_acc_h<false>(st, 1.f, ps);                 // (st = p SP already)
@@ -299,7 +339,8 @@ __global__ __launch_bounds__(512, 1) void tattn3_kernel(TattnParams p, const uns
             //      normalisation, the descale of P and V and the pre-scale of O are one multiplier
             {
                 f16x8 os[2][2];
-                split_acc_h<true>(oT, (SO / SV) / l, os);             // (l = SP x the sum of the probabilities)
+                // (l = SP x the sum of the probabilities; with the fp32 P V product oT carries 1 / PROJ_DESCALE instead of SV)
+                split_acc_h<true>(oT, (DPC_TATTN_PV_F32 != 0 ? SO * PROJ_DESCALE : SO / SV) / l, os);
                 f16x8 wo[2 * NTC][2];
 #pragma unroll
                 for (int g = 0; g < 2 * NTC; ++g) {                 // group g = (column tile g / 2, k-step g % 2)
@@ -702,7 +743,7 @@ int launch_tattn3(const TattnParams& p_in, const unsigned char* wq3, const unsig
         ncu = prop.multiProcessorCount;
     }
     if (p.F > 32) {
-        const long long gridw = std::min<long long>((p.npix + 3) / 4, ncu);
+        const long long gridw = std::min<long long>((p.npix + 3) / 4, cu_budget(ncu));
         if (C == 64) {
             launch_t3w<64, 0>(p, wq3, wo3, nullptr, gridw, s);
         } else {
@@ -713,7 +754,7 @@ int launch_tattn3(const TattnParams& p_in, const unsigned char* wq3, const unsig
         DPC_LAUNCH_CHECK();
         return DPC_OK;
     }
-    const long long grid = std::min<long long>((p.npix + 7) / 8, ncu);
+    const long long grid = std::min<long long>((p.npix + 7) / 8, cu_budget(ncu));
     if (C == 64) {
         launch_t3<64, 0>(p, wq3, wo3, nullptr, grid, s);
     } else {

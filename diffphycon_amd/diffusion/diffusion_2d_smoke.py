@@ -163,6 +163,7 @@ class GaussianDiffusion(nn.Module):
             self.to(device)
         # counter-based noise: keyed (seed, global trajectory index, draw)
         self.noise_seed = None          # None -> torch.initial_seed() at sample() time
+        self.step_callback = None       # host-side hook at the top of every sampling step (the smoke entry script's evaluator overlap)
         self.traj_offset = 0            # global index of this rank's first trajectory
         self.noise_epoch = None         # None -> advances by one per sample() call (like the reference's torch RNG, two
         self._calls = 0                 #   consecutive calls differ); an int pins it (callers that key by global trajectory)
@@ -260,6 +261,8 @@ class GaussianDiffusion(nn.Module):
         x = self.sample_noise([b, f, c, h, w], device)
         x[:, 0, 0] = init
         for t in reversed(range(0, self.num_timesteps)):
+            if self.step_callback is not None:
+                self.step_callback()
             t_b = torch.full((b,), t, device=device, dtype=torch.long)
             eps_j, eps_w = self._denoisers(x, t_b)
             z = self.sample_noise([b, f, c, h, w], device) if t > 0 else None
@@ -281,6 +284,8 @@ class GaussianDiffusion(nn.Module):
         img[:, 0, 0] = init
         ac = self._host["alphas_cumprod"]
         for time, time_next in time_pairs:
+            if self.step_callback is not None:
+                self.step_callback()
             t_b = torch.full((batch,), time, device=device, dtype=torch.long)
             eps_j, eps_w = self._denoisers(img, t_b)
             c = self._coef_ddpm(time, design_guidance, w_energy)

@@ -42,6 +42,12 @@ int dpc_version(void);
  * The Python binding refuses a library with n != 0 unless DPC_ALLOW_PACKED_FP32=1 (packed fp32 VALU instructions return wrong lanes
  * when a second kernel is resident on the GPU).  The reference has no counterpart (a build-hygiene entry, not an operator). */
 const char* dpc_build_info(void);
+/* CU budget of the persistent ("one workgroup per CU") kernels -- 3x3x3 / (1,3,3) convolutions, fused temporal attention: 0 = every CU
+ * of the device (default), else at most `cus` (rounded down to a multiple of 8, one share per XCD) workgroups per launch.  The smoke
+ * entry script sets 192 while a batch's PDE rollouts (64 CUs for ~2 s: csrc/smoke_rollout.hip) run on a side stream under the next
+ * batch's sampling (inference/inference_2d_smoke.py InferencePipeline.run; reference schedule: inference_2d_smoke.py:259-271 runs them
+ * one after the other).  Results do not depend on the value (the tile -> workgroup map changes, no arithmetic does). */
+int dpc_set_cu_budget(int cus);
 const char* dpc_last_error(void);
 
 /* Arithmetic mode of the GEMM-shaped op families ("conv" 3x3x3 convolutions, "igemm" implicit-GEMM ops, "attn" fused

@@ -23,7 +23,7 @@ from diffphycon_amd.dataset.data_2d import Smoke, SyntheticSmoke  # noqa: E402
 from diffphycon_amd.dataset.apps.evaluate_solver import init_sim_128, init_velocity_, solver_batch  # noqa: E402
 from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, SmokeGuidance, Trainer  # noqa: E402
 from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D  # noqa: E402
-from diffphycon_amd import parallel  # noqa: E402
+from diffphycon_amd import _lib, parallel  # noqa: E402
 from filepath import SMOKE_DATA_PATH, SMOKE_RESULTS_PATH  # noqa: E402
 
 
@@ -82,13 +82,12 @@ class InferencePipeline(object):
         output[:, :, -1] = output[:, :, -1].mean((-2, -1)).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 64, 64)
         return output
 
-    def multi_evaluate(self, pred, data, plot=False, method="DDPM"):
-        """pred [B,32,6,64,64], data [B,256,6,64,64]: roll the sampled controls through the PDE solver and score
-        (:317-427).  Returns per-batch means (J_total, J_target, J_energy, mse, n_l2) as arrays of length 1."""
+    def _evaluate_enqueue(self, pred, data):
+        """Device work of multi_evaluate (:317-427) on the CURRENT stream, no host read: roll the sampled controls through the PDE
+        solver and form the per-trajectory metric rows [B, 5] = (J_total, J_target, J_energy, mse, n_l2)."""
         k = int(data.shape[-1] / pred.shape[-1])
         data = data.to(pred.device)
         pred[:, 0, 0] = data[:, 0, 0, ::k, ::k]
-        start = time.time()
         pred_ = pred.detach().clone()
         pred_[:, :, 3:5, 8:56, 8:56] = 0                                         # indirect control (:330)
         dens, _, vel, smoke = solver_batch(self.sim, init_velocity_(), data[:, 0, 0], pred_[:, :, 3], pred_[:, :, 4],
@@ -99,7 +98,6 @@ class InferencePipeline(object):
         cur[:, :, 1], cur[:, :, 2] = vel[..., 0], vel[..., 1]
         cur[:, :, 3], cur[:, :, 4] = pred_[:, :, 3].double(), pred_[:, :, 4].double()
         cur[:, :, 5] = smoke[:, :, None, None]
-        print(f"Time cost: {time.time() - start}")
         mask = torch.ones_like(pred)
         mask[:, 0] = 0
         p, d = pred * mask, cur * mask
@@ -109,16 +107,55 @@ class InferencePipeline(object):
         J_target = -d[:, -1, -1, 0, 0]
         J_energy = d[:, :, 3:5].square().mean((1, 2, 3, 4))
         J_total = J_target + self.args_general.w_energy * J_energy
-        rows = torch.stack((J_total, J_target, J_energy, mse, n_l2), dim=1)          # [B, 5] per-trajectory metric rows
+        return torch.stack((J_total, J_target, J_energy, mse, n_l2), dim=1)          # [B, 5] per-trajectory metric rows
+
+    def _evaluate_report(self, rows, start):
+        """The host side of multi_evaluate: ONE read of the batch means, the reference's print lines."""
         self.last_rows = rows               # run() gathers them ONCE after its loop (ranks may own different batch counts)
         m = rows.mean(0).cpu().numpy()
+        print(f"Time cost: {time.time() - start}")
         print("J_total=J_target+w*J_energy=", m[1], "+", self.args_general.w_energy, "*", m[2], "=", m[0])
         print("mse=", m[3], "normalized_l2=", m[4])
         return tuple(np.array([v]) for v in m)
 
+    def multi_evaluate(self, pred, data, plot=False, method="DDPM"):
+        """pred [B,32,6,64,64], data [B,256,6,64,64]: roll the sampled controls through the PDE solver and score
+        (:317-427).  Returns per-batch means (J_total, J_target, J_energy, mse, n_l2) as arrays of length 1."""
+        start = time.time()
+        return self._evaluate_report(self._evaluate_enqueue(pred, data), start)
+
     def run(self, dataloader):
+        """The reference's loop (:259-271) samples a batch, evaluates it, samples the next.  Here the evaluation of batch i -- 64 CUs
+        for ~2 s: one persistent workgroup per rollout -- is enqueued on a SIDE stream and runs under batch i + 1's sampling (r05;
+        `--overlap_evaluator False` restores the serial schedule).  Same kernels, same inputs: the metric rows are bit-identical to
+        the serial run (tests/test_gpu_inference_scripts.py).  While a rollout is in flight the persistent sampling kernels are
+        told to size their grids for the CUs that are left (include/dpc.h: dpc_set_cu_budget)."""
         J = {k: [] for k in ("J_total", "J_target", "J_energy", "mse", "n_l2")}
         rows = []
+        overlap = bool(getattr(self.args_general, "overlap_evaluator", True)) and len(dataloader) > 1
+        side = torch.cuda.Stream(device=self.device) if overlap else None
+        budget = int(os.environ.get("DPC_EVALUATOR_CU_BUDGET", "192"))
+        L = _lib.lib()
+        pending = None                      # (rows on the side stream, start time, tensors the side stream still reads)
+
+        def release_budget():
+            # Called at the top of every sampling step while rollouts are in flight.  Grid sizes are fixed when a launch is ENQUEUED, and
+            # the host runs ahead of the GPU: it first waits for the sampling stream (a ~0.1 ms bubble per step, for the ~9 steps the
+            # rollouts last), then asks whether the rollouts are done and, if so, gives the persistent kernels the whole device back.
+            torch.cuda.current_stream().synchronize()
+            if pending is not None and pending[3].query():
+                L.dpc_set_cu_budget(0)
+                self.model[0].step_callback = None
+
+        def finish(pend):
+            side.synchronize()
+            L.dpc_set_cu_budget(0)
+            self.model[0].step_callback = None
+            out = self._evaluate_report(pend[0], pend[1])
+            rows.append(self.last_rows)
+            for key, v in zip(J, out):
+                J[key].append(v)
+
         for i, (state, sim_id) in enumerate(dataloader):
             print(f"Batch No.{i}")
             ids = [int(v) for v in sim_id]
@@ -127,10 +164,28 @@ class InferencePipeline(object):
             self.model[0].traj_offset, self.model[0].noise_epoch = ids[0], 0
             pred = self.run_model(state)
             print("pred shape: ", pred.shape)
-            out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
-            rows.append(self.last_rows)
-            for key, v in zip(J, out):
-                J[key].append(v)
+            if not overlap:
+                out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
+                rows.append(self.last_rows)
+                for key, v in zip(J, out):
+                    J[key].append(v)
+                continue
+            if pending is not None:
+                finish(pending)              # batch i - 1's rollouts ran beside this batch's sampling
+            done = torch.cuda.Event()
+            done.record()                    # pred is complete on the sampling stream
+            start = time.time()
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                r = self._evaluate_enqueue(pred, state)
+                rolled = torch.cuda.Event()
+                rolled.record()              # on the side stream: the rollouts (and the metric rows) are complete
+            pending = (r, start, pred, rolled)
+            if budget > 0:
+                L.dpc_set_cu_budget(budget)  # the next batch's persistent kernels leave the rollouts' CUs alone ...
+                self.model[0].step_callback = release_budget          # ... until the rollouts are done
+        if pending is not None:
+            finish(pending)
         if getattr(self.args_general, "world_size", 1) > 1:
             # one RCCL all_gather pair for the whole run (variable row counts per rank, global trajectory order); the summary
             # is then the mean over ALL trajectories (= the reference's mean of batch means when batches are equal-sized)
@@ -138,6 +193,7 @@ class InferencePipeline(object):
             local = torch.cat(rows) if rows else torch.zeros(0, 5, dtype=torch.float64, device=dev)
             allrows = parallel.gather_metric_rows(local).mean(0).cpu().numpy()
             J = {k: [np.array([v])] for k, v in zip(J, allrows)}
+        self.all_rows = rows                 # per-batch [B, 5] metric rows of this rank, in batch order
         summary = ",\n".join(f"{k}: {np.stack(v).mean(0)}" for k, v in J.items())
         print("Final results!\nNumber of upsampling times: 0\n" + summary)
         with open(os.path.join(self.results_path, "results.txt"), "a") as f:
@@ -192,6 +248,8 @@ def build_parser():
     parser.add_argument("--diffusion_model_w_path", default=os.path.join(SMOKE_RESULTS_PATH, "checkpoints/w_models"), type=str)
     parser.add_argument("--diffusion_w_checkpoint", default=17, type=int)
     parser.add_argument("--using_ddim", default=True, type=eval)
+    parser.add_argument("--overlap_evaluator", default=True, type=eval,
+                        help="(not in the reference) run batch i's PDE rollouts on a side stream under batch i + 1's sampling; results are bit-identical")
     parser.add_argument("--ddim_eta", default=1., type=float)
     parser.add_argument("--w_prob_exp", default=0.97, type=float)
     parser.add_argument("--ddim_sampling_steps", default=100, type=int)

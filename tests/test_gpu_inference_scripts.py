@@ -34,6 +34,39 @@ def test_smoke_inference_script_ddim(tmp_path):
     assert any(f == "results.txt" for _, _, fs in os.walk(tmp_path) for f in fs)
 
 
+def test_smoke_pipeline_evaluator_overlap_equals_the_serial_schedule(tmp_path):
+    """r05: InferencePipeline.run enqueues batch i's PDE rollouts + metric rows on a side stream under batch i + 1's
+    sampling, with the persistent kernels' CU budget lowered while the rollouts are in flight.  Same kernels, same inputs: the
+    per-trajectory metric rows (J_total, J_target, J_energy, mse, n_l2) of every batch and the summary are BIT-identical to the serial
+    schedule (--overlap_evaluator False = the reference's loop, inference_2d_smoke.py:259-271)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "inference"))
+    import inference_2d_smoke as S
+    from diffphycon_amd import _lib
+    res = {}
+    for overlap in (False, True, True):
+        a = S.build_parser().parse_args(["--synthetic", "True", "--n_test", "3", "--batch_size", "1", "--ddim_sampling_steps", "3",
+                                         "--overlap_evaluator", str(overlap), "--inference_result_path", str(tmp_path / str(overlap))])
+        a.device, a.rank, a.world_size = torch.device("cuda:0"), 0, 1
+        a.inference_result_subpath = str(tmp_path / f"r{overlap}")
+        torch.manual_seed(0)
+        loader, rescaler = S.load_data(a)
+        diffusion, design_fn = S.load_model(a, rescaler, a.w_energy, w_init=a.w_init)
+        ppl = S.InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": a.design_guidance}, rescaler,
+                                  results_path=a.inference_result_subpath, args_general=a)
+        J = ppl.run(loader)
+        assert diffusion[0].step_callback is None                     # the hook is gone and the budget is back to the whole device
+        rows = torch.cat(ppl.all_rows).cpu().numpy()
+        assert rows.shape == (3, 5) and np.isfinite(rows).all()
+        res.setdefault(overlap, []).append((rows, {k: np.asarray(v) for k, v in J.items()}))
+    _lib.lib().dpc_set_cu_budget(0)
+    serial, over = res[False][0], res[True]
+    for rows, J in over:
+        assert np.array_equal(rows, serial[0])
+        assert all(np.array_equal(J[k], serial[1][k]) for k in J)
+
+
 def test_jellyfish_inference_script(tmp_path):
     out = run(["inference/inference_2d_jellyfish.py", "--synthetic", "True", "--batch_size", "1", "--num_batches", "1",
                "--frames", "4", "--image_size", "64", "--timesteps", "3", "--inference_result_path", str(tmp_path)], ROOT)

@@ -26,8 +26,6 @@ lib = os.path.join(B.LIBDIR, f"libdpc_{tag}.so")
 subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
 # the variant carries an honest stamp too (a variant WITH packed fp32 ops then needs DPC_ALLOW_PACKED_FP32=1 to load: _lib._check_build)
 n_packed, n_objs = B.scan_packed_fp32(lib)
-stamp = B._stamp_object(n_packed, n_objs, [*B.FLAGS, *extra])
-vstamp = os.path.join(objdir, "build_stamp.o")
-os.replace(stamp, vstamp)
+vstamp = B._stamp_object(n_packed, n_objs, [*B.FLAGS, *extra], outdir=objdir)
 subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, vstamp])
 print(lib, f"({n_packed} packed fp32 instructions)")

@@ -1,0 +1,82 @@
+// Library-free reproducer of the shared-GPU hazard of packed fp32 VALU instructions on gfx950.
+// VICTIM: a pure-VALU kernel, y = (x - mean) * rstd * gamma on float2 values with (mean, rstd) straight from one 8-byte load -- the
+// expression of libdpc's LayerNorm apply, which hipcc compiles to v_pk_add_f32 / v_pk_mul_f32 with op_sel broadcasts.  AGGRESSOR: any
+// second kernel resident at the same time (here: LDS traffic + MFMAs on a second stream).  The victim runs once alone (reference bits),
+// then REPS times beside the aggressor; every repetition is compared bit for bit.  Build twice (tools/pk_repro/run.sh):
+//   hipcc --offload-arch=gfx950 -O3 pk_repro.hip -o pk_repro_pk                                                   (packed ops)
+//   hipcc --offload-arch=gfx950 -O3 -Xclang -target-feature -Xclang -packed-fp32-ops pk_repro.hip -o pk_repro_nopk   (none)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 2; } } while (0)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void victim(const f2* __restrict__ x, const f2* __restrict__ stats, const f2* __restrict__ gamma,
+                                              f2* __restrict__ y, long long rows, int c2) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < rows * c2; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c2;
+        const f2 st = stats[row];                         // (mean, rstd) as ONE dwordx2 load
+        const f2 g = gamma[i % c2];
+        y[i] = (x[i] - st.x) * st.y * g;                  // -> v_pk_add_f32 / v_pk_mul_f32 ... op_sel (see the ISA: run.sh greps it)
+    }
+}
+
+__global__ __launch_bounds__(256) void aggressor(float* __restrict__ out, int iters) {
+    __shared__ float buf[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) buf[i] = (float)(i & 63) * 0.01f;
+    __syncthreads();
+    f16v acc = {0};
+    h8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = (_Float16)(0.01f * (threadIdx.x + k)); b[k] = (_Float16)(0.02f * k); }
+    for (int it = 0; it < iters; ++it) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        const float v = buf[(threadIdx.x * 33 + it * 7) & 8191];
+        buf[(threadIdx.x * 17 + it * 5) & 8191] = v + acc[0] * 1e-9f;
+        a[it & 7] = (_Float16)v;
+    }
+    __syncthreads();
+    out[blockIdx.x * 256 + threadIdx.x] = acc[3] + buf[threadIdx.x];
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 400, c2 = 32;              // 64 channels per row
+    const long long rows = 1 << 20, n = rows * c2;
+    std::vector<f2> hx(n), hs(rows), hg(c2);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f; };
+    for (auto& v : hx) { v.x = rnd(); v.y = rnd(); }
+    for (auto& v : hs) { v.x = rnd() * 0.1f; v.y = 1.0f + rnd(); }
+    for (auto& v : hg) { v.x = 1.0f + rnd(); v.y = 1.0f + rnd(); }
+    f2 *x, *st, *g, *y; float* ao;
+    CK(hipMalloc(&x, n * 8)); CK(hipMalloc(&st, rows * 8)); CK(hipMalloc(&g, c2 * 8)); CK(hipMalloc(&y, n * 8)); CK(hipMalloc(&ao, 4096 * 256 * 4));
+    CK(hipMemcpy(x, hx.data(), n * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(st, hs.data(), rows * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(g, hg.data(), c2 * 8, hipMemcpyHostToDevice));
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    std::vector<f2> ref(n), got(n);
+    hipLaunchKernelGGL(victim, dim3(2048), dim3(256), 0, s1, x, st, g, y, rows, c2);
+    CK(hipStreamSynchronize(s1));
+    CK(hipMemcpy(ref.data(), y, n * 8, hipMemcpyDeviceToHost));
+    int bad_alone = 0, bad_shared = 0;
+    long long first = -1;
+    for (int mode = 0; mode < 2; ++mode)                 // 0: alone again (control), 1: beside the aggressor
+        for (int r = 0; r < reps; ++r) {
+            CK(hipMemsetAsync(y, 0, n * 8, s1));
+            if (mode) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 0, s2, ao, 20000);
+            hipLaunchKernelGGL(victim, dim3(2048), dim3(256), 0, s1, x, st, g, y, rows, c2);
+            CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2));
+            CK(hipMemcpy(got.data(), y, n * 8, hipMemcpyDeviceToHost));
+            if (memcmp(got.data(), ref.data(), n * 8)) {
+                (mode ? bad_shared : bad_alone)++;
+                if (first < 0)
+                    for (long long i = 0; i < n; ++i)
+                        if (memcmp(&got[i], &ref[i], 8)) { first = i; printf("first wrong element %lld (thread-in-wave %lld): got (%g, %g) expected (%g, %g)\n",
+                                                                             i, i % 64, got[i].x, got[i].y, ref[i].x, ref[i].y); break; }
+            }
+        }
+    printf("victim alone: %d of %d repetitions differ from the first run; beside the aggressor: %d of %d differ\n", bad_alone, reps, bad_shared, reps);
+    return 0;
+}
