@@ -327,7 +327,7 @@ long long conv3x6_tiles_per_sample(int F, int H, int W);
 // stats [B][groups][2] (mean, rstd) and, when coef != null, the per-channel coefficient table consumed by Conv3hParams::in_coef
 int launch_gn_finalize_fused(const float* part, int B, long long tiles, int C, int groups, long long rows_per_sample,
                              const float* gamma, const float* beta, const float* scale_shift, float* stats, float* coef,
-                             hipStream_t s);
+                             hipStream_t s, long long entries = 0 /* partial-sum entries per sample; 0: tiles * 2 */);
 // GroupNorm apply (+ scale/shift, SiLU, residual) from finished statistics
 int launch_gn_apply(const float* x, float* out, const float* resid, const float* stats, const float* gamma,
                     const float* beta, const float* scale_shift, int B, long long rows_per_sample, int C, int groups,
@@ -343,6 +343,8 @@ int launch_pack_weights_f3(const float* w, void* wp, int N, int Npad, int K, hip
 long long conv3f3_gn_entries(int F, int H, int W, int N, int Npad);
 // loader-wave / persistent form of the big-tile kernel (conv3f3c.hip); same GroupNorm partial-sum layout
 bool conv3f3c_supported(const Conv3hParams& p);
+bool conv3f3c_flat_gn_ok(int N, int Npad, int H, int W);      // the (1,3,3) form with per-image GroupNorm hooks takes this shape
+long long conv3f3c_flat_gn_entries(int H, int W);             // its partial-sum entries per image
 int launch_conv3f3c(const Conv3hParams& p, hipStream_t s);     // GroupNorm partial-sum entries per (sample, channel)
 // Winograd F(2,3)-over-frames form of the f16x3 3x3x3 convolution (conv3w.hip): 2/3 of the matrix products of the direct kernels.
 // Taken by launch_conv3f3 when Conv3hParams::wpw is set and the shape qualifies (shape-only rule).

@@ -613,6 +613,7 @@ int launch_conv3f3(const Conv3hParams& p, hipStream_t s) {
     const int variant = flat ? 2 : conv3f3_variant(p.F, p.H, p.W, p.N, p.Npad);
     static const int flat_c = debug_switch("DPC_CONV2D_LOADER_WAVES", 1);
     if (variant == 2 && (!flat || flat_c) && conv3f3c_supported(pd)) return launch_conv3f3c(pd, s);     // loader-wave / persistent form
+    DPC_REQUIRE(!flat || !(p.gn_part || p.in_coef), "conv3f3: the per-image GroupNorm hooks of the (1,3,3) form exist in conv3f3c only");
     if (variant == 2) {
         const int tf = wide ? 4 : 8;
         const long long tiles = (long long)p.B * ((p.F + tf - 1) / tf) * (p.H / 8) * (p.W / 8);

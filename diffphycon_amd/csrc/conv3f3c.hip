@@ -22,6 +22,14 @@
 // Arithmetic, weight pack ([tap][chunk][n][2 planes][16] fp16, launch_pack_weights_f3) and GroupNorm partial-sum layout are
 // those of conv3f3b_kernel; results are bit-identical to it except for the summation order inside the GroupNorm partials.
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:189-204).
+// r05, KD = 1 (the 2-D nets' 3x3 convolutions, one IMAGE per frame: model/burgers_1d/unet.py:134-191 Block / ResnetBlock; the jellyfish
+// surrogates): GroupNorm is per image there, so the fusion of the 3-D path needs per-frame bookkeeping --
+//   * statistics epilogue: one partial-sum entry per (image, 8 x 8 plane tile) = [F][nth * ntw][N][2] (a wave reduces the two slabs of
+//     each of its two frames separately: 2 x the shuffles of the 3-D form);
+//   * fused-input loader: a loader thread's items are grouped by frame (item i = frame i >> 1, point slot (ltid >> 2) + 64 (i & 1)), so
+//     the folded coefficients (A, B) log2(e) of launch_gn_finalize_fused's second table are fetched once per (frame, chunk) and the
+//     activation is z = fma(x, A, B), SiLU(y) sa = z rcp(fma(exp2(-z), c, c)), c = log2(e) / sa -- the operand pre-scale is free, as in
+//     conv3w.hip's loader.  Zero padding applies to the ACTIVATED tensor: out-of-image points stay 0.
 #include "common.h"
 #include "f3c.h"
 
@@ -75,32 +83,52 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
     if (wave >= 4) {
         // ======================================================================================= loader waves
         const int ltid = tid - 256;
-        int hdst[HLOADS];
+        // item -> (frame, point, channel quad).  KD = 3: items in point order.  KD = 1: grouped by frame (see the header): every item of a
+        // thread knows its frame at compile time, which is what the per-image GroupNorm coefficients of the fused input need.
+        constexpr int NITEM = KD == 1 ? HF * 2 : HLOADS;
+        auto item_point = [&](int i, int& pf, int& ph, int& pw, int& quad, bool& valid) {
+            if (KD == 1) {
+                const int slot = (ltid >> 2) + 64 * (i & 1);
+                pf = i >> 1; ph = slot / 10; pw = slot % 10; quad = ltid & 3;
+                valid = slot < 100;
+                if (!valid) { ph = 0; pw = 0; }
+            } else {
+                const int q = ltid + 256 * i, pt = q >> 2;
+                pf = pt / 100; ph = (pt / 10) % 10; pw = pt % 10; quad = q & 3;
+                valid = pt < NLOG;
+            }
+        };
+        int hdst[NITEM];
+        unsigned hvalid = 0;
 #pragma unroll
-        for (int i = 0; i < HLOADS; ++i) {
-            const int q = ltid + 256 * i, pt = q >> 2, quad = q & 3;
-            const int pf = pt / 100, ph = (pt / 10) % 10, pw = pt % 10;
+        for (int i = 0; i < NITEM; ++i) {
+            int pf, ph, pw, quad;
+            bool valid;
+            item_point(i, pf, ph, pw, quad, valid);
             hdst[i] = slot0(pf, ph, pw, quad >> 1) + (quad & 1) * 8;
+            if (valid) hvalid |= 1u << i;
         }
         const int hslot = (ltid & 3) * 4;
         unsigned hokm = 0;
-        int hpt[HLOADS];
+        int hpt[NITEM];
         const float* xb0 = nullptr;
         const float* xb1 = nullptr;
-        int b_cur = 0;
+        int b_cur = 0, f0_cur = 0;
         auto setup_tile = [&](int j) {
             int n0, w0, h0, f0, b;
             decode(j, n0, w0, h0, f0, b);
             b_cur = b;
+            f0_cur = f0;
             xb0 = p.a0 + (long long)b * p.F * p.H * p.W * p.C0;
             xb1 = p.a1 ? p.a1 + (long long)b * p.F * p.H * p.W * p.C1 : nullptr;
             hokm = 0;
 #pragma unroll
-            for (int i = 0; i < HLOADS; ++i) {
-                const int pt = (ltid + 256 * i) >> 2;
-                const int pf = pt / 100, ph = (pt / 10) % 10, pw = pt % 10;
+            for (int i = 0; i < NITEM; ++i) {
+                int pf, ph, pw, quad;
+                bool valid;
+                item_point(i, pf, ph, pw, quad, valid);
                 const int f = f0 - FPAD + pf, h = h0 - 1 + ph, w = w0 - 1 + pw;
-                if (pt < NLOG && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) hokm |= 1u << i;
+                if (valid && (unsigned)f < (unsigned)p.F && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) hokm |= 1u << i;
                 hpt[i] = (f * p.H + h) * p.W + w;
             }
         };
@@ -113,18 +141,43 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
             if (c < p.C0) { src = xb0; cs = p.C0; cc = c; }
             else { src = xb1; cs = p.C1; cc = c - p.C0; }
             const bool cok = c < K;
-            f32x4 hreg[HLOADS];
+            f32x4 hreg[NITEM];
 #pragma unroll
-            for (int i = 0; i < HLOADS; ++i) {
+            for (int i = 0; i < NITEM; ++i) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cok && ((hokm >> i) & 1)) v = *reinterpret_cast<const f32x4*>(src + (long long)hpt[i] * cs + cc);
                 hreg[i] = v;
             }
-            if (p.in_coef && cok) {
+            bool scaled = false;                          // true: hreg already carries the operand pre-scale sa
+            if (KD == 1) {
+                if (p.in_coef && cok) {
+                    // per-image folded coefficients (second table of launch_gn_finalize_fused, "batch" = the F images of this launch)
+                    const float cl = 1.4426950408889634f / sa;
+                    const f32x4* tab = reinterpret_cast<const f32x4*>(p.in_coef + (long long)p.F * K * 5);
+#pragma unroll
+                    for (int pf = 0; pf < HF; ++pf) {
+                        const int img = min(f0_cur + pf, p.F - 1);
+                        const f32x4* cf = tab + ((long long)img * (K >> 2) + (c >> 2)) * 2;
+                        const f32x4 A = cf[0], Bc = cf[1];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int i = 2 * pf + u;
+                            const bool in = (hokm >> i) & 1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float z = __builtin_fmaf(hreg[i][e], A[e], Bc[e]);
+                                const float y = z * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(-z), cl, cl));
+                                hreg[i][e] = in ? y : 0.f;
+                            }
+                        }
+                    }
+                    scaled = true;
+                }
+            } else if (p.in_coef && cok) {
                 const f32x4* cf = reinterpret_cast<const f32x4*>(p.in_coef) + ((long long)b_cur * (K >> 2) + (c >> 2)) * 5;
                 const f32x4 mu = cf[0], ga = cf[1], be = cf[2], sc = cf[3], sh = cf[4];
 #pragma unroll
-                for (int i = 0; i < HLOADS; ++i) {
+                for (int i = 0; i < NITEM; ++i) {
                     if ((hokm >> i) & 1) {
                         f32x4 y = (hreg[i] - mu) * ga + be;
                         y = y * sc + sh;
@@ -135,10 +188,10 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < HLOADS; ++i) {
-                if (ltid + 256 * i < NLOG * 4) {
+            for (int i = 0; i < NITEM; ++i) {
+                if ((hvalid >> i) & 1) {
                     uint2 p1, p2;
-                    split2(hreg[i] * sa, p1, p2);
+                    split2(scaled ? hreg[i] : hreg[i] * sa, p1, p2);
                     const int d = hdst[i] + boff;
                     *reinterpret_cast<uint2*>(halo + d) = p1;
                     *reinterpret_cast<uint2*>(halo + (d ^ 32)) = p2;
@@ -293,62 +346,76 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
         // ---- epilogue: lane = point (slab mt, lane_hw(l31)), registers 4g..4g+3 = channels nt*32 + 8g + 4hh .. +3
         const int nbase = n0 + wn * (BN / WN) + 4 * hh;
         const long long tile = ((long long)(f0 / TF) * nth + h0 / 8) * ntw + w0 / 8;
-        float* gdst = p.gn_part ? p.gn_part + (((long long)b * ((long long)ntf * nth * ntw) + tile) * WM + wm) * p.N * 2 : nullptr;
+        // GroupNorm partial sums of the OUTPUT: KD = 3 one entry per (tile, wave row) over the wave's 4 slabs (statistics per sample);
+        // KD = 1 one entry per (image, plane tile): the wave's two frames are two images, NGRP = 2 groups of two slabs each
+        constexpr int NGRP = KD == 1 ? 2 : 1, MPG = MT / NGRP;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float gs[16], gq[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gs[r] = 0.f; gq[r] = 0.f; }
             f32x4 bv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 bv[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbase + nt * 32 + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int f = f0 + wm * 2 + (mt >> 1);
-                if (f >= p.F) continue;                  // partial frame tile
-                float* base = p.out + ((((long long)b * p.F + f) * p.H + h0 + 4 * (mt & 1) + lh) * p.W + w0 + lw) * p.N + nbase + nt * 32;
+            for (int grp = 0; grp < NGRP; ++grp) {
+                float gs[16], gq[16];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
+                for (int r = 0; r < 16; ++r) { gs[r] = 0.f; gq[r] = 0.f; }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[mt][nt][4 * g + e] * descale + bv[g][e];
-                        gs[4 * g + e] += v[e];
-                        gq[4 * g + e] += v[e] * v[e];
-                    }
-                    *reinterpret_cast<f32x4*>(base + 8 * g) = v;
-                }
-            }
-            if (gdst) {
-                // GroupNorm statistics of the OUTPUT: per channel, this wave's 4 slabs x 32 points.  Transpose tree over the 32
-                // lanes of a half-wave: each step halves the registers a lane still owns and adds its partner's copy of them
-                // (8 + 4 + 2 + 1 shuffles), a last plain exchange folds lanes 2k, 2k + 1; lane l31 then holds the total of
-                // register r = 8 b4 + 4 b3 + 2 b2 + b1 (b_i = bit i of l31).  Fixed order: deterministic.
-                float tot[2];
+                for (int mi = 0; mi < MPG; ++mi) {
+                    const int mt = grp * MPG + mi;
+                    const int f = f0 + wm * 2 + (mt >> 1);
+                    if (f >= p.F) continue;                  // partial frame tile
+                    float* base = p.out + ((((long long)b * p.F + f) * p.H + h0 + 4 * (mt & 1) + lh) * p.W + w0 + lw) * p.N + nbase + nt * 32;
 #pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    float* x = which ? gq : gs;
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
 #pragma unroll
-                    for (int half = 8; half >= 1; half >>= 1) {
-                        const bool up = (l31 & (half * 2)) != 0;          // lane bit 4, 3, 2, 1 for half = 8, 4, 2, 1
-#pragma unroll
-                        for (int i = 0; i < half; ++i) {
-                            const float send = up ? x[i] : x[i + half];
-                            const float keep = up ? x[i + half] : x[i];
-                            x[i] = keep + __shfl_xor(send, half * 2, 64);
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[mt][nt][4 * g + e] * descale + bv[g][e];
+                            gs[4 * g + e] += v[e];
+                            gq[4 * g + e] += v[e] * v[e];
                         }
+                        *reinterpret_cast<f32x4*>(base + 8 * g) = v;
                     }
-                    tot[which] = x[0] + __shfl_xor(x[0], 1, 64);
                 }
-                if ((l31 & 1) == 0) {
-                    const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + ((l31 >> 1) & 1);
-                    const int n = n0 + wn * (BN / WN) + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    gdst[n * 2] = tot[0];
-                    gdst[n * 2 + 1] = tot[1];
+                float* gdst = nullptr;
+                if (p.gn_part) {
+                    if (KD == 1) {
+                        const int f = f0 + wm * 2 + grp;
+                        if (f < p.F) gdst = p.gn_part + (((long long)f * (nth * ntw) + (h0 / 8) * ntw + w0 / 8) * p.N) * 2;
+                    } else {
+                        gdst = p.gn_part + (((long long)b * ((long long)ntf * nth * ntw) + tile) * WM + wm) * p.N * 2;
+                    }
                 }
+                if (p.gn_part) {                         // (wave-uniform: every lane takes part in the shuffles)
+                    // Transpose tree over the 32 lanes of a half-wave: each step halves the registers a lane still owns and adds its
+                    // partner's copy of them (8 + 4 + 2 + 1 shuffles), a last plain exchange folds lanes 2k, 2k + 1; lane l31 then holds
+                    // the total of register r = 8 b4 + 4 b3 + 2 b2 + b1 (b_i = bit i of l31).  Fixed order: deterministic.
+                    float tot[2];
+#pragma unroll
+                    for (int which = 0; which < 2; ++which) {
+                        float* x = which ? gq : gs;
+#pragma unroll
+                        for (int half = 8; half >= 1; half >>= 1) {
+                            const bool up = (l31 & (half * 2)) != 0;          // lane bit 4, 3, 2, 1 for half = 8, 4, 2, 1
+#pragma unroll
+                            for (int i = 0; i < half; ++i) {
+                                const float send = up ? x[i] : x[i + half];
+                                const float keep = up ? x[i + half] : x[i];
+                                x[i] = keep + __shfl_xor(send, half * 2, 64);
+                            }
+                        }
+                        tot[which] = x[0] + __shfl_xor(x[0], 1, 64);
+                    }
+                    if (gdst && (l31 & 1) == 0) {
+                        const int r = ((l31 >> 4) & 1) * 8 + ((l31 >> 3) & 1) * 4 + ((l31 >> 2) & 1) * 2 + ((l31 >> 1) & 1);
+                        const int n = n0 + wn * (BN / WN) + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        gdst[n * 2] = tot[0];
+                        gdst[n * 2 + 1] = tot[1];
+                    }
+                }
+                asm volatile("" ::: "memory");
             }
-            asm volatile("" ::: "memory");
         }
         if (j < 2) stamp();
     }
@@ -370,9 +437,17 @@ bool conv3f3c_supported(const Conv3hParams& p) {
     static const int ok = debug_switch("DPC_CONV3F3C", 1);
     const bool wide = p.Npad % 128 == 0 && p.N > 64;
     const int tf = wide ? 4 : 8;
-    return ok && p.H % 8 == 0 && p.W % 8 == 0 && p.N % 64 == 0 && p.N == p.Npad && (p.F % tf == 0 || p.F >= 16) &&
+    // (kd == 1: any image count -- partial frame tiles -- so that the kernel choice, and the GroupNorm fusion that rests on it, depends on
+    //  the layer shape only, never on the batch)
+    return ok && p.H % 8 == 0 && p.W % 8 == 0 && p.N % 64 == 0 && p.N == p.Npad && (p.kd == 1 || p.F % tf == 0 || p.F >= 16) &&
            p.C0 % 4 == 0 && p.C1 % 4 == 0;
 }
+
+bool conv3f3c_flat_gn_ok(int N, int Npad, int H, int W) {
+    static const int ok = debug_switch("DPC_CONV3F3C", 1) && debug_switch("DPC_CONV2D_LOADER_WAVES", 1) && debug_switch("DPC_CONV2D_FUSED_GN", 1);
+    return ok && H % 8 == 0 && W % 8 == 0 && N % 64 == 0 && N == Npad;
+}
+long long conv3f3c_flat_gn_entries(int H, int W) { return (long long)(H / 8) * (W / 8); }
 
 int launch_conv3f3c(const Conv3hParams& p, hipStream_t s) {
     using namespace f3c;

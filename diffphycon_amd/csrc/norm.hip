@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void gn_onepass_kernel(const float* x, float* 
 __global__ __launch_bounds__(1024) void gn_finalize_fused_kernel(const float* __restrict__ part, float* __restrict__ stats,
                                                                 float* __restrict__ coef, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
-                                                                const float* __restrict__ scale_shift, long long tiles, int C,
+                                                                const float* __restrict__ scale_shift, long long nslab, int C,
                                                                 int groups, long long R, int B) {
     // one WORKGROUP per (sample, group): 1024 threads stream the partials with 4 independent accumulators each (the kernel
     // sits on the conv1 -> conv2 dependency chain and is pure load latency: one wave per group took 48 us, 256 threads 11 us)
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_fused_kernel(const float* __
     const int wid = blockIdx.x;
     const int b = wid / groups, g = wid % groups;
     const int cpg = C / groups;
-    const long long nslab = tiles * 2, total = nslab * cpg;
+    const long long total = nslab * cpg;
     const float* base = part + ((long long)b * nslab * C + (long long)g * cpg) * 2;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     auto at = [&](long long i) -> const float* {
@@ -403,12 +403,13 @@ __global__ __launch_bounds__(1024) void gn_finalize_fused_kernel(const float* __
 
 int launch_gn_finalize_fused(const float* part, int B, long long tiles, int C, int groups, long long R,
                              const float* gamma, const float* beta, const float* scale_shift, float* stats, float* coef,
-                             hipStream_t s) {
+                             hipStream_t s, long long entries) {
     DPC_REQUIRE(groups >= 1 && C % groups == 0 && C % 4 == 0, "gn_finalize_fused: groups must divide C, C % 4 == 0");
     if (B == 0) return DPC_OK;
-    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * tiles * 2 * C * 2, s);
+    const long long nslab = entries > 0 ? entries : tiles * 2;        // partial-sum entries per sample
+    ProfScope prof(PROF_GN, 0, 4.0 * (double)B * nslab * C * 2, s);
     hipLaunchKernelGGL(gn_finalize_fused_kernel, dim3(B * groups), dim3(1024), 0, s, part, stats, coef, gamma, beta,
-                       scale_shift, tiles, C, groups, R, B);
+                       scale_shift, nslab, C, groups, R, B);
     DPC_LAUNCH_CHECK();
     return DPC_OK;
 }

@@ -27,6 +27,7 @@ struct dpc_unet2d_s {
     size_t ws_need = 0;
     dpc::Modes modes{2, 2, 2, 2};                                  // captured at create time (common.h: Modes)
     bool fused_attn = true;      // DPC_UNFUSED_ATTN=1 (captured at create) selects the unfused composition of LinearAttention (A/B tests)
+    bool fused_gn = true;        // DPC_UNFUSED_GN=1: standalone GroupNorm passes instead of the conv-fused form of the 16 x 128 / 8 x 64 levels
     bool taps_on = false;
     struct Tap { std::unique_ptr<dpc::DevBuf> buf; size_t floats = 0; };
     std::map<std::string, Tap> taps;
@@ -188,9 +189,41 @@ struct Runner2D {
             ss = ar.allocf((long long)mb * 2 * Cout);
             RUN(launch_small_linear(temb, raw(p + ".mlp.1.weight"), raw(p + ".mlp.1.bias"), ss, mb, h->cfg.dim * 4, 2 * Cout, 1, 0, s));
         }
+        const bool same = (C1 == 0 && C0 == Cout);
+        const PackedConv* c1 = conv(p + ".block1.proj.weight");
+        const PackedConv* c2 = conv(p + ".block2.proj.weight");
+        // r05: GroupNorm fused around the two 3x3 convolutions where both run on the halo-tile kernel (H, W multiples of 8: the 16 x 128 and
+        // 8 x 64 levels of the Burgers nets): per-image statistics come out of the conv epilogues, block1's normalise + (scale, shift) +
+        // SiLU is applied inside block2's halo load (h1 never exists in activated form), only block2's apply (+ residual) stays a
+        // streaming pass -- 3 passes over the activation per ResnetBlock instead of 7 (unet.py:134-191).  Shape-only rule.
+        const bool fused = h->fused_gn && igemm_mode_default() != 0 && C0 % 4 == 0 && C1 % 4 == 0 &&
+                           conv2d_gn_fusable(Cout, igemm_npad(Cout), Hl, Wl);     // (modes + shapes only: the dry run decides alike)
+        if (fused) {
+            if (!dry() && !rc && !(c1 && c2 && c1->flat3 && c2->flat3)) rc = fail(DPC_ERR_STATE, "unet2d: " + p + ": 3x3 pack for the halo kernel missing");
+            const long long ent = conv3f3c_flat_gn_entries(Hl, Wl), R = (long long)Hl * Wl;
+            float* raw1 = ar.allocf(P * Cout);
+            float* part = ar.allocf((long long)mb * ent * Cout * 2);
+            float* stats = ar.allocf((long long)mb * Cout * 2);
+            float* coef = ar.allocf((long long)mb * Cout * 7);
+            float* raw2 = (same && dst == x0) ? ar.allocf(P * Cout) : dst;
+            if (c1 && c2) {
+                RUN(run_conv(*c1, x0, x1, C0, C1, raw(p + ".block1.proj.bias"), nullptr, raw1, mb, 1, Hl, Wl, Hl, Wl, nullptr, nullptr, 0, 0, 0,
+                             s, part, nullptr));
+                RUN(launch_gn_finalize_fused(part, mb, 0, Cout, h->cfg.groups, R, raw(p + ".block1.norm.weight"), raw(p + ".block1.norm.bias"),
+                                             ss, stats, coef, s, ent));
+                RUN(run_conv(*c2, raw1, nullptr, Cout, 0, raw(p + ".block2.proj.bias"), nullptr, raw2, mb, 1, Hl, Wl, Hl, Wl, nullptr, nullptr, 0,
+                             0, 0, s, part, coef));
+                RUN(launch_gn_finalize_fused(part, mb, 0, Cout, h->cfg.groups, R, nullptr, nullptr, nullptr, stats, nullptr, s, ent));
+                RUN(launch_gn_apply(raw2, dst, same ? x0 : nullptr, stats, raw(p + ".block2.norm.weight"), raw(p + ".block2.norm.bias"), nullptr,
+                                    mb, R, Cout, h->cfg.groups, s));
+                if (!same)
+                    convolve(p + ".res_conv.weight", p + ".res_conv.bias", x0, x1, C0, C1, dst, dst, Hl, Wl, Hl, Wl, nullptr, nullptr, 0);
+            }
+            ar.release(m);
+            return;
+        }
         float* h1 = ar.allocf(P * Cout);
         block(p + ".block1", x0, x1, C0, C1, Cout, h1, h1, nullptr, ss, Hl, Wl);
-        const bool same = (C1 == 0 && C0 == Cout);
         if (same) {
             float* h2 = (dst == x0) ? ar.allocf(P * Cout) : dst;
             block(p + ".block2", h1, nullptr, Cout, 0, Cout, h2, dst, x0, nullptr, Hl, Wl);     // + x (identity res_conv)
@@ -390,6 +423,7 @@ int dpc_unet2d_create(const dpc_unet2d_cfg* cfg, dpc_unet2d_t* out) {
     h->cfg = *cfg;
     h->modes = modes_global();
     h->fused_attn = !debug_switch("DPC_UNFUSED_ATTN", 0);
+    h->fused_gn = !debug_switch("DPC_UNFUSED_GN", 0);
     if (h->cfg.out_dim <= 0) h->cfg.out_dim = h->cfg.channels;
     h->dims.push_back(cfg->dim);
     for (int i = 0; i < cfg->n_mults; ++i) h->dims.push_back(cfg->dim * cfg->dim_mults[i]);

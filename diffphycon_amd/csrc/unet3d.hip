@@ -154,6 +154,10 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
     return launch_pack_weights_x6(w, pc.wp6.p, N, pc.Npad, K, s);
 }
 
+bool conv2d_gn_fusable(int N, int Npad, int H, int W) {
+    return conv_mode_default() == 2 && conv3f3c_flat_gn_ok(N, Npad, H, W);
+}
+
 bool conv_can_fuse_gn_residual(const PackedConv& pc, long long rows_per_sample) {
     static const int ok = debug_switch("DPC_FUSE_GN_RES", 1);
     return ok && !pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && pc.N % 4 == 0 && rows_per_sample % 128 == 0;
@@ -189,7 +193,11 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
     DPC_REQUIRE(C0 + C1 == pc.K, "conv: channel mismatch");
     DPC_REQUIRE(!gn_raw || (!pc.halo && !pc.flat3 && igemm_mode_default() == 2 && pc.wp6g.p && gn_coef),
                 "conv: the fused GroupNorm residual needs the f16x3 implicit GEMM");
-    DPC_REQUIRE(!(gn_part || in_coef) || (pc.halo && conv_mode_default() >= 1), "conv: GroupNorm fusion needs the split-operand conv path");
+    static const int flat_ok = debug_switch("DPC_CONV2D_HALO", 1);
+    const bool flat_halo = flat_ok && pc.flat3 && !a0_stride && !resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo && Hi % 8 == 0 &&
+                           Wi % 8 == 0 && C0 % 4 == 0 && C1 % 4 == 0;
+    DPC_REQUIRE(!(gn_part || in_coef) || (pc.halo && conv_mode_default() >= 1) || (flat_halo && conv2d_gn_fusable(pc.N, pc.Npad, Hi, Wi)),
+                "conv: GroupNorm fusion needs the split-operand halo-tile conv path");
     if (pc.halo) {
         DPC_REQUIRE(!resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo, "conv3h: plain 3x3x3 conv only");
         Conv3hParams q{};
@@ -210,15 +218,14 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
         }
         return launch_conv3h(q, s);
     }
-    static const int flat_ok = debug_switch("DPC_CONV2D_HALO", 1);
-    if (flat_ok && pc.flat3 && !a0_stride && !resid && !ln_stats && out_mode == 0 && Hi == Ho && Wi == Wo && Hi % 8 == 0 && Wi % 8 == 0 &&
-        C0 % 4 == 0 && C1 % 4 == 0) {
+    if (flat_halo) {
         // (1,3,3) convolution on the halo-tile kernel: frames = the BF images (no coupling), shape-only rule (any batch size)
         Conv3hParams q{};
         q.a0 = a0; q.a1 = a1; q.C0 = C0; q.C1 = C1; q.wp = reinterpret_cast<const float*>(pc.wp3.p); q.bias = bias; q.out = out;
         q.B = 1; q.F = BF; q.H = Hi; q.W = Wi; q.N = pc.N; q.Npad = pc.Npad; q.kchunks = (pc.K + 15) / 16; q.kd = 1;
         q.act_scale = act_scale;
-        if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, nullptr, 0, s)) return r;
+        q.gn_part = gn_part; q.in_coef = in_coef;          // per-IMAGE GroupNorm hooks of conv3f3c's (1,3,3) form (r05)
+        if (int r = range_check_note(a0, (long long)BF * Hi * Wi, C0, a1, (long long)BF * Hi * Wi, C1, in_coef, (long long)Hi * Wi, s)) return r;
         return launch_conv3f3(q, s);
     }
     IgemmParams p{};

@@ -61,5 +61,8 @@ int run_conv(const PackedConv& pc, const float* a0, const float* a1, int C0, int
              const float* in_coef = nullptr, const float* gn_raw = nullptr, const float* gn_coef = nullptr, float act_scale = 0.f, int a0_stride = 0);
 // true when run_conv can take (gn_raw, gn_coef): the f16x3 implicit GEMM with whole 128-row tiles per sample
 bool conv_can_fuse_gn_residual(const PackedConv& pc, long long rows_per_sample);
+// (1,3,3) convolution of a 2-D net with N output channels on H x W images: does it run on the loader-wave halo kernel, whose r05 form
+// emits per-IMAGE GroupNorm partial sums and applies a per-image GroupNorm + SiLU to its input?  Shape-only (never the batch).
+bool conv2d_gn_fusable(int N, int Npad, int H, int W);
 
 }  // namespace dpc

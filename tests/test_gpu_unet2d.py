@@ -89,6 +89,40 @@ def test_fused_linear_attention_equals_the_unfused_composition(dev, monkeypatch)
     assert note_error("unet2d fused vs unfused linear attention", rel(outs["0"], outs["1"])) < 1.6e-6
 
 
+@pytest.mark.parametrize("groups,B", [(1, 1), (1, 3), (8, 5), (8, 21)])
+def test_conv_fused_groupnorm_equals_the_standalone_passes(groups, B, dev, monkeypatch):
+    """r05: at the 16 x 128 and 8 x 64 levels (H, W multiples of 8) the ResnetBlocks' GroupNorms are fused around the two 3x3 convolutions
+    (model/burgers_1d/unet.py:134-191): per-IMAGE statistics from the (1,3,3) halo kernel's epilogue, block1's normalise + (scale, shift)
+    + SiLU inside block2's halo load.  DPC_UNFUSED_GN=1 (captured when the handle is created) keeps the standalone statistics / apply
+    passes: same arithmetic, different summation order of the statistics and an approximate reciprocal in the fused SiLU -> equal to
+    rounding.  Batch sizes that leave partial frame tiles (1, 3, 5, 21 images against tiles of 4 / 8), both group counts the scripts use;
+    the oracle as the third party; and a trajectory's result must not depend on its batch."""
+    from conftest import note_error
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from oracle import unet2d as U
+    mults = (1, 2, 4)
+    cfg = U.Unet2DConfig(dim=64, dim_mults=mults, resnet_block_groups=groups)
+    sd = U.synthetic_state_dict(cfg, seed=13)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 2, 16, 128, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    outs = {}
+    for unfused in ("0", "1"):
+        monkeypatch.setenv("DPC_UNFUSED_GN", unfused)
+        m = Unet2D(dim=64, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=groups)
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        outs[unfused] = m(x.to(dev), t.to(dev))
+        if unfused == "0" and B > 1:
+            assert torch.equal(m(x[B - 1:].to(dev), t[B - 1:].to(dev)), outs["0"][B - 1:])      # the last image alone: same bits
+    assert not torch.equal(outs["0"], outs["1"]), "the switch did not select a different path"
+    assert note_error(f"unet2d conv-fused vs standalone GroupNorm g{groups} B{B}", rel(outs["0"], outs["1"])) < 5e-6
+    if B <= 3:
+        with torch.no_grad():
+            ref = U.unet2d_forward(sd, cfg, x, t)
+        assert note_error(f"unet2d conv-fused GroupNorm vs oracle g{groups} B{B}", rel(outs["0"].cpu(), ref)) < 1e-5
+
+
 @pytest.mark.parametrize("hw", [(8, 20), (16, 24)])
 def test_fused_linear_attention_on_ragged_token_counts(hw, dev, monkeypatch):
     """The fused block masks the tokens of its last 32-token tile: 8 x 20 images give 160 tokens (5 tiles) at C = 64 and, one level
