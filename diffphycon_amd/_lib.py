@@ -125,6 +125,10 @@ _SIGNATURES = {
     "dpc_conv_free": (None, [_P]),
     "dpc_conv_run": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 5 + [_P, _P, _I, _I, _I, C.c_float, _I, _P]),
     "dpc_gn_workspace_bytes": (_Z, [_I, _I]),
+    "dpc_conv_gn_fusable": (C.c_int, [_P, _I, _I]),
+    "dpc_conv_gn_entries": (_L, [_I, _I]),
+    "dpc_conv_run_gn": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "dpc_gn_finalize_fused": (C.c_int, [_P, _I, _L, _I, _I, _L, _P, _P, _P, _P, _P, _P]),
     "dpc_gn_stats": (C.c_int, [_P, _P, _I, _L, _I, _I, _P, _Z, _P]),
     "dpc_gn_apply": (C.c_int, [_P] * 7 + [_I, _L, _I, _I, _P]),
     "dpc_gn_silu_bwd": (C.c_int, [_P] * 8 + [_I, _L, _I, _I, _P, _Z, _P]),

@@ -654,6 +654,30 @@ int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1,
                     (hipStream_t)stream, nullptr, nullptr, nullptr, nullptr, act_scale, a0_stride);
 }
 
+// ---- GroupNorm fused around a ResnetBlock's two 3x3 convolutions (r05; see include/dpc.h)
+int dpc_conv_gn_fusable(dpc_conv_t h, int H, int W) {
+    if (!h) return 0;
+    ModeScope scope(h->modes);
+    return (h->pc.flat3 && conv2d_gn_fusable(h->pc.N, h->pc.Npad, H, W)) ? 1 : 0;
+}
+int64_t dpc_conv_gn_entries(int H, int W) { return conv3f3c_flat_gn_entries(H, W); }
+int dpc_conv_run_gn(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, float* out, int images, int H, int W,
+                    float* gn_part, const float* in_coef, dpc_stream_t stream) {
+    DPC_REQUIRE(h && a0 && out && images >= 1, "conv_run_gn: null argument");
+    DPC_REQUIRE(gn_part || in_coef, "conv_run_gn: neither statistics output nor input coefficients (use dpc_conv_run)");
+    DPC_REQUIRE(!in_coef || (!a1 && C1 == 0), "conv_run_gn: a fused input normalisation needs a single source");
+    DPC_REQUIRE(dpc_conv_gn_fusable(h, H, W), "conv_run_gn: this convolution / image size does not take the halo kernel (dpc_conv_gn_fusable)");
+    ModeScope scope(h->modes);
+    return run_conv(h->pc, a0, a1, C0, C1, bias, nullptr, out, images, 1, H, W, H, W, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream, gn_part,
+                    in_coef, nullptr, nullptr, 0.f, 0);
+}
+int dpc_gn_finalize_fused(const float* part, int images, int64_t entries, int C, int groups, int64_t rows_per_image, const float* gamma,
+                          const float* beta, const float* scale_shift, float* stats, float* coef, dpc_stream_t stream) {
+    DPC_REQUIRE(part && stats && images >= 1 && entries >= 1, "gn_finalize_fused: bad argument");
+    DPC_REQUIRE(!coef || (gamma && beta), "gn_finalize_fused: the coefficient table needs gamma and beta");
+    return launch_gn_finalize_fused(part, images, 0, C, groups, rows_per_image, gamma, beta, scale_shift, stats, coef, (hipStream_t)stream, entries);
+}
+
 size_t dpc_gn_workspace_bytes(int B, int C) { return std::max(gn_workspace_bytes(B, C), gn_bwd_workspace_bytes(B, C)) + 256; }
 
 int dpc_gn_stats(const float* x, float* stats, int B, int64_t R, int C, int groups, void* ws, size_t ws_bytes, dpc_stream_t stream) {

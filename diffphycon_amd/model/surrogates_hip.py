@@ -25,6 +25,7 @@ from .. import _lib
 # arithmetic of the convolutions: "f16x3" (default; 22-bit operands, 3 MFMAs per product, the 3x3 convs on the LDS halo-tile
 # kernel), "x6" (bf16x6: fp32-equivalent products, 6 MFMAs, implicit GEMM only) or "f32"
 _MODE = os.environ.get("DPC_SURROGATE_MODE", "f16x3")
+_FUSED_GN = os.environ.get("DPC_SURROGATE_FUSED_GN", "1") != "0"       # A/B: 0 keeps the standalone GroupNorm statistics / apply passes
 
 
 class _Calibration:
@@ -111,6 +112,20 @@ class _Conv:
                                            images, Hi, Wi, Ho, Wo, _lib.ptr(ln[0]) if ln else None, _lib.ptr(ln[1]) if ln else None,
                                            out_mode, par[0], par[1], self.act_scale, a0_stride, _lib.stream()))
         return out
+
+
+def _conv_gn_fusable(conv, H, W):
+    return bool(_lib.lib().dpc_conv_gn_fusable(conv.h, H, W))
+
+
+def _conv_run_gn(conv, a0, images, H, W, a1=None, bias=None, part=None, in_coef=None):
+    """dpc_conv_run_gn: the 3x3 convolution with the per-image GroupNorm hooks of the halo kernel (include/dpc.h)."""
+    C0 = a0.shape[-1]
+    C1 = a1.shape[-1] if a1 is not None else 0
+    out = torch.empty(images * H * W, conv.N, device=a0.device, dtype=torch.float32)
+    _lib.check(_lib.lib().dpc_conv_run_gn(conv.h, _lib.ptr(a0), _lib.ptr(a1), C0, C1, _lib.ptr(bias), _lib.ptr(out), images, H, W,
+                                          _lib.ptr(part), _lib.ptr(in_coef), _lib.stream()))
+    return out
 
 
 def _DConv(w, **kw):
@@ -235,6 +250,24 @@ class _Res:
     def forward(self, x0, x1, temb, n, H, W):
         ctx, R, Cc = self.ctx, H * W, self.Cout
         ss = ctx.linear(temb, self.mlp[0], self.mlp[1], in_act=1) if (self.mlp is not None and temb is not None) else None
+        if _FUSED_GN and _conv_gn_fusable(self.c1, H, W) and _conv_gn_fusable(self.c2, H, W):
+            # r05: statistics from the conv epilogues, block1's GroupNorm + (scale, shift) + SiLU inside conv2's halo load: the activated
+            # tensor a1 never exists (the backward recomputes it from raw1 / st1 as before) -- 3 passes per block instead of 7
+            L = _lib.lib()
+            ent = L.dpc_conv_gn_entries(H, W)
+            part = torch.empty(n * ent * Cc * 2, device=x0.device)
+            coef = torch.empty(n * Cc * 7, device=x0.device)
+            st1 = torch.empty(n, ctx.groups, 2, device=x0.device)
+            st2 = torch.empty(n, ctx.groups, 2, device=x0.device)
+            raw1 = _conv_run_gn(self.c1, x0, n, H, W, a1=x1, bias=self.b1, part=part)
+            _lib.check(L.dpc_gn_finalize_fused(_lib.ptr(part), n, ent, Cc, ctx.groups, R, _lib.ptr(self.g1), _lib.ptr(self.be1), _lib.ptr(ss),
+                                               _lib.ptr(st1), _lib.ptr(coef), _lib.stream()))
+            raw2 = _conv_run_gn(self.c2, raw1, n, H, W, bias=self.b2, part=part, in_coef=coef)
+            _lib.check(L.dpc_gn_finalize_fused(_lib.ptr(part), n, ent, Cc, ctx.groups, R, None, None, None, _lib.ptr(st2), None, _lib.stream()))
+            res = self.cr(x0, n, H, W, a1=x1, bias=self.br) if self.cr is not None else x0
+            out = ctx.gn_apply(raw2, st2, self.g2, self.be2, None, n, R, Cc, resid=res)
+            self.tape = (raw1, st1, raw2, st2, ss, n, H, W)
+            return out
         raw1 = self.c1(x0, n, H, W, a1=x1, bias=self.b1)
         st1 = ctx.gn_stats(raw1, n, R, Cc)
         a1 = ctx.gn_apply(raw1, st1, self.g1, self.be1, ss, n, R, Cc)

@@ -243,6 +243,20 @@ void dpc_conv_free(dpc_conv_t h);
 int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, const float* resid, float* out,
                  int images, int Hi, int Wi, int Ho, int Wo, const float* ln_stats, const float* ln_gamma, int out_mode, int par_a,
                  int par_b, float act_scale, int a0_stride, dpc_stream_t stream);
+/* GroupNorm fused around the two 3x3 convolutions of a ResnetBlock (r05; diffusion_2d_jellyfish.py:122-148 Block / ResnetBlock, the same
+ * fusion the 2-D denoiser uses internally): where dpc_conv_gn_fusable says the convolution runs on the halo-tile kernel (f16x3 mode, 3x3
+ * stride 1, N % 64 == 0, H % 8 == 0, W % 8 == 0 -- shape only, never the batch), dpc_conv_run_gn
+ *   - with gn_part != NULL also emits per-image partial sums of its OUTPUT, [images][dpc_conv_gn_entries(H, W)][N][2] floats, from which
+ *     dpc_gn_finalize_fused forms stats [images][groups][2] = (mean, rstd) -- no statistics pass over the tensor -- and, with coef != NULL
+ *     ([images * C * 7] floats), the per-channel coefficients of GN -> x (scale + 1) + shift (scale_shift [images][2C] or NULL);
+ *   - with in_coef != NULL (that table) applies GroupNorm + (scale, shift) + SiLU to its INPUT on the fly: the activated tensor of
+ *     block1 never exists in HBM.  Zero padding applies to the activated tensor, as in the reference. */
+int dpc_conv_gn_fusable(dpc_conv_t h, int H, int W);
+int64_t dpc_conv_gn_entries(int H, int W);
+int dpc_conv_run_gn(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, float* out, int images, int H, int W,
+                    float* gn_part, const float* in_coef, dpc_stream_t stream);
+int dpc_gn_finalize_fused(const float* part, int images, int64_t entries, int C, int groups, int64_t rows_per_image, const float* gamma,
+                          const float* beta, const float* scale_shift, float* stats, float* coef, dpc_stream_t stream);
 /* GroupNorm (:140-157 Block): stats [B][groups][2] = (mean, rstd); apply: out = SiLU(GN(x) * (scale + 1) + shift) (+ resid),
  * scale_shift [B][2C] or NULL; backward: dx and (dss != NULL) d scale_shift [B][2C] given dy. */
 size_t dpc_gn_workspace_bytes(int B, int C);

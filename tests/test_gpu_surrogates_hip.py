@@ -97,6 +97,55 @@ def test_conv_run_forward_and_data_gradient(dev, mode):
     assert rel(out, F.conv2d(x0, w3, b[:3])) < tol
 
 
+@pytest.mark.parametrize("n,H,W,Ci,Co,groups", [(5, 16, 24, 64, 64, 8), (3, 8, 64, 128, 128, 1), (9, 16, 16, 64, 128, 8)])
+def test_conv_with_per_image_groupnorm_hooks(dev, n, H, W, Ci, Co, groups):
+    """r05 (include/dpc.h: dpc_conv_run_gn / dpc_gn_finalize_fused): the (1,3,3) halo kernel emits per-IMAGE GroupNorm partial sums of its
+    output and applies a per-image GroupNorm + (scale, shift) + SiLU to its input.  Against fp64 torch: conv1 -> [statistics] ->
+    GroupNorm -> x (scale + 1) + shift -> SiLU -> conv2, image counts that leave partial frame tiles (5, 3, 9 images against tiles of 8 / 4),
+    both column-tile widths.  The conv outputs themselves must equal dpc_conv_run's bit for bit (same kernel, same MFMA order)."""
+    from diffphycon_amd import _lib
+    from diffphycon_amd.model import surrogates_hip as SH
+    torch.manual_seed(n + Ci)
+    L = _lib.lib()
+    x = torch.randn(n, Ci, H, W, device=dev, dtype=torch.float64)
+    w1 = torch.randn(Co, Ci, 3, 3, device=dev, dtype=torch.float64) * (2.0 / (9 * Ci)) ** 0.5
+    w2 = torch.randn(Co, Co, 3, 3, device=dev, dtype=torch.float64) * (2.0 / (9 * Co)) ** 0.5
+    b1, b2 = torch.randn(Co, device=dev, dtype=torch.float64) * 0.1, torch.randn(Co, device=dev, dtype=torch.float64) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(Co, device=dev, dtype=torch.float64), 0.2 * torch.randn(Co, device=dev, dtype=torch.float64)
+    ss = 0.3 * torch.randn(n, 2 * Co, device=dev, dtype=torch.float64)
+    raw1_ref = F.conv2d(x, w1, b1, padding=1)
+    gn = F.group_norm(raw1_ref, groups, gamma, beta, eps=1e-5)
+    act = F.silu(gn * (ss[:, :Co, None, None] + 1) + ss[:, Co:, None, None])
+    raw2_ref = F.conv2d(act, w2, b2, padding=1)
+    c1, c2 = SH._Conv(w1.float()), SH._Conv(w2.float())
+    assert SH._conv_gn_fusable(c1, H, W) and SH._conv_gn_fusable(c2, H, W)
+    ent = L.dpc_conv_gn_entries(H, W)
+    assert ent == (H // 8) * (W // 8)
+    part = torch.full((n * ent * Co * 2,), float("nan"), device=dev)
+    coef = torch.empty(n * Co * 7, device=dev)
+    st = torch.empty(n, groups, 2, device=dev)
+    raw1 = SH._conv_run_gn(c1, cl(x), n, H, W, bias=b1.float(), part=part)
+    assert torch.equal(raw1, c1(cl(x), n, H, W, bias=b1.float()))
+    assert torch.isfinite(part).all()                                   # every (image, tile) entry was written
+    _lib.check(L.dpc_gn_finalize_fused(_lib.ptr(part), n, ent, Co, groups, H * W, _lib.ptr(gamma.float()), _lib.ptr(beta.float()),
+                                       _lib.ptr(ss.float().contiguous()), _lib.ptr(st), _lib.ptr(coef), _lib.stream()))
+    r = raw1_ref.reshape(n, groups, -1)
+    assert (st[:, :, 0].double() - r.mean(-1)).abs().max().item() < 2e-6 * r.abs().max().item()
+    assert rel(st[:, :, 1], (r.var(-1, unbiased=False) + 1e-5).rsqrt()) < 5e-6
+    part2 = torch.full_like(part, float("nan"))
+    raw2 = SH._conv_run_gn(c2, raw1, n, H, W, bias=b2.float(), part=part2, in_coef=coef)
+    assert rel(uncl(raw2, n, H, W), raw2_ref) < 1e-5
+    st2 = torch.empty(n, groups, 2, device=dev)
+    _lib.check(L.dpc_gn_finalize_fused(_lib.ptr(part2), n, ent, Co, groups, H * W, None, None, None, _lib.ptr(st2), None, _lib.stream()))
+    r2 = raw2_ref.reshape(n, groups, -1)
+    assert (st2[:, :, 0].double() - r2.mean(-1)).abs().max().item() < 1e-5 * r2.abs().max().item()
+    # an image's result does not depend on the images around it (partial frame tiles, per-image coefficients)
+    k = n - 1
+    one = SH._conv_run_gn(c2, raw1[k * H * W:].contiguous(), 1, H, W, bias=b2.float(), part=torch.empty(ent * Co * 2, device=dev),
+                          in_coef=torch.cat([coef[:n * Co * 5].reshape(n, -1)[k], coef[n * Co * 5:].reshape(n, -1)[k]]).contiguous())
+    assert torch.equal(one, raw2[k * H * W:])
+
+
 def test_groupnorm_silu_backward(dev):
     from diffphycon_amd.model import surrogates_hip as SH
     torch.manual_seed(1)
