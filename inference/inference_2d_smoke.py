@@ -73,7 +73,7 @@ class InferencePipeline(object):
 
     def run_model(self, state):
         """state: not rescaled [B, 256, 6, 64, 64] -> sampled + rescaled [B, 32, 6, 64, 64]   (:179-197)"""
-        state = state.to(self.args_general.device)[:, ::8]
+        state = state[:, ::8].to(self.args_general.device)          # (slice on the host: 0.2 GB over PCIe instead of 1.6 GB; same values)
         output = self.model[0].sample(
             batch_size=state.shape[0], design_fn=self.args["design_fn"], design_guidance=self.args["design_guidance"],
             low=None, init=state[:, 0, 0] / self.RESCALER[:, 0, 0], init_u=state[:, 0, 0],
@@ -86,11 +86,11 @@ class InferencePipeline(object):
         """Device work of multi_evaluate (:317-427) on the CURRENT stream, no host read: roll the sampled controls through the PDE
         solver and form the per-trajectory metric rows [B, 5] = (J_total, J_target, J_energy, mse, n_l2)."""
         k = int(data.shape[-1] / pred.shape[-1])
-        data = data.to(pred.device)
-        pred[:, 0, 0] = data[:, 0, 0, ::k, ::k]
+        d00 = data[:, 0, 0].to(pred.device)          # (only the initial density is read: 1 MB instead of the batch's 1.6 GB)
+        pred[:, 0, 0] = d00[:, ::k, ::k]
         pred_ = pred.detach().clone()
         pred_[:, :, 3:5, 8:56, 8:56] = 0                                         # indirect control (:330)
-        dens, _, vel, smoke = solver_batch(self.sim, init_velocity_(), data[:, 0, 0], pred_[:, :, 3], pred_[:, :, 4],
+        dens, _, vel, smoke = solver_batch(self.sim, init_velocity_(), d00, pred_[:, :, 3], pred_[:, :, 4],
                                            per_timelength=256, frame_stride=8, space_stride=2, want_zero_density=False)
         B = pred.shape[0]
         cur = torch.empty(B, 32, 6, 64, 64, dtype=torch.float64, device=pred.device)     # data_current (:388-390)
@@ -102,7 +102,9 @@ class InferencePipeline(object):
         mask[:, 0] = 0
         p, d = pred * mask, cur * mask
         diff = p - d
-        mse = torch.cat((diff[:, :, :3], diff[:, :, [-1]]), dim=2).square().mean((1, 2, 3, 4))
+        # (diff[:, :, -1:] and not the reference's diff[:, :, [-1]]: a list index becomes an index tensor that is copied to the device with a
+        #  BLOCKING copy on this stream -- the host then waits for the rollouts in front of it; same elements, same order)
+        mse = torch.cat((diff[:, :, :3], diff[:, :, -1:]), dim=2).square().mean((1, 2, 3, 4))
         n_l2 = diff[:, :, :3].square().sum((1, 2, 3, 4)).sqrt() / d[:, :, :3].square().sum((1, 2, 3, 4)).sqrt()
         J_target = -d[:, -1, -1, 0, 0]
         J_energy = d[:, :, 3:5].square().mean((1, 2, 3, 4))
@@ -137,13 +139,21 @@ class InferencePipeline(object):
         budget = int(os.environ.get("DPC_EVALUATOR_CU_BUDGET", "192"))
         L = _lib.lib()
         pending = None                      # (rows on the side stream, start time, tensors the side stream still reads)
+        tlog = os.environ.get("DPC_PIPELINE_LOG") == "1"
+        t_run0 = time.time()
+
+        def note(msg):
+            if tlog:
+                print(f"[pipeline +{time.time() - t_run0:8.3f} s] {msg}", file=sys.stderr, flush=True)
 
         def release_budget():
             # Called at the top of every sampling step while rollouts are in flight.  Grid sizes are fixed when a launch is ENQUEUED, and
             # the host runs ahead of the GPU: it first waits for the sampling stream (a ~0.1 ms bubble per step, for the ~9 steps the
             # rollouts last), then asks whether the rollouts are done and, if so, gives the persistent kernels the whole device back.
             torch.cuda.current_stream().synchronize()
-            if pending is not None and pending[3].query():
+            done_now = pending is not None and pending[3].query()
+            note(f"sampling step begins; rollouts of the previous batch {'DONE' if done_now else 'still running'}")
+            if done_now:
                 L.dpc_set_cu_budget(0)
                 self.model[0].step_callback = None
 
@@ -158,11 +168,13 @@ class InferencePipeline(object):
 
         for i, (state, sim_id) in enumerate(dataloader):
             print(f"Batch No.{i}")
+            note(f"batch {i}: loader returned")
             ids = [int(v) for v in sim_id]
             assert ids == list(range(ids[0], ids[0] + len(ids))), "batches must hold consecutive simulation ids"
             # noise keyed by the global simulation id (Philox): independent of batch size and of the sharding over ranks
             self.model[0].traj_offset, self.model[0].noise_epoch = ids[0], 0
             pred = self.run_model(state)
+            note(f"batch {i}: run_model returned")
             print("pred shape: ", pred.shape)
             if not overlap:
                 out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
@@ -180,6 +192,7 @@ class InferencePipeline(object):
                 r = self._evaluate_enqueue(pred, state)
                 rolled = torch.cuda.Event()
                 rolled.record()              # on the side stream: the rollouts (and the metric rows) are complete
+            note(f"batch {i}: evaluator enqueued on the side stream")
             pending = (r, start, pred, rolled)
             if budget > 0:
                 L.dpc_set_cu_budget(budget)  # the next batch's persistent kernels leave the rollouts' CUs alone ...

@@ -127,8 +127,9 @@ def test_conv_with_per_image_groupnorm_hooks(dev, n, H, W, Ci, Co, groups):
     raw1 = SH._conv_run_gn(c1, cl(x), n, H, W, bias=b1.float(), part=part)
     assert torch.equal(raw1, c1(cl(x), n, H, W, bias=b1.float()))
     assert torch.isfinite(part).all()                                   # every (image, tile) entry was written
-    _lib.check(L.dpc_gn_finalize_fused(_lib.ptr(part), n, ent, Co, groups, H * W, _lib.ptr(gamma.float()), _lib.ptr(beta.float()),
-                                       _lib.ptr(ss.float().contiguous()), _lib.ptr(st), _lib.ptr(coef), _lib.stream()))
+    g32, be32, ss32 = gamma.float(), beta.float(), ss.float().contiguous()       # (named: a temporary would be freed behind _lib.ptr)
+    _lib.check(L.dpc_gn_finalize_fused(_lib.ptr(part), n, ent, Co, groups, H * W, _lib.ptr(g32), _lib.ptr(be32), _lib.ptr(ss32), _lib.ptr(st),
+                                       _lib.ptr(coef), _lib.stream()))
     r = raw1_ref.reshape(n, groups, -1)
     assert (st[:, :, 0].double() - r.mean(-1)).abs().max().item() < 2e-6 * r.abs().max().item()
     assert rel(st[:, :, 1], (r.var(-1, unbiased=False) + 1e-5).rsqrt()) < 5e-6
@@ -141,8 +142,8 @@ def test_conv_with_per_image_groupnorm_hooks(dev, n, H, W, Ci, Co, groups):
     assert (st2[:, :, 0].double() - r2.mean(-1)).abs().max().item() < 1e-5 * r2.abs().max().item()
     # an image's result does not depend on the images around it (partial frame tiles, per-image coefficients)
     k = n - 1
-    one = SH._conv_run_gn(c2, raw1[k * H * W:].contiguous(), 1, H, W, bias=b2.float(), part=torch.empty(ent * Co * 2, device=dev),
-                          in_coef=torch.cat([coef[:n * Co * 5].reshape(n, -1)[k], coef[n * Co * 5:].reshape(n, -1)[k]]).contiguous())
+    coef_k = torch.cat([coef[:n * Co * 5].reshape(n, -1)[k], coef[n * Co * 5:].reshape(n, -1)[k]]).contiguous()
+    one = SH._conv_run_gn(c2, raw1[k * H * W:].contiguous(), 1, H, W, bias=b2.float(), part=torch.empty(ent * Co * 2, device=dev), in_coef=coef_k)
     assert torch.equal(one, raw2[k * H * W:])
 
 
