@@ -78,13 +78,17 @@ class InferencePipeline(object):
             batch_size=state.shape[0], design_fn=self.args["design_fn"], design_guidance=self.args["design_guidance"],
             low=None, init=state[:, 0, 0] / self.RESCALER[:, 0, 0], init_u=state[:, 0, 0],
             control=state[:, :, 3:5] / self.RESCALER[:, :, 3:5])
+        if getattr(self, "_side_stream", None) is not None:
+            # overlapped schedule: the torch element-wise kernels below must not run beside the previous batch's rollouts (torch's kernels
+            # contain packed fp32 instructions: DESIGN.md 6.2).  Normally the rollouts ended ~24 s ago; a very short chain waits here.
+            torch.cuda.current_stream().wait_stream(self._side_stream)
         output = output * self.RESCALER
         output[:, :, -1] = output[:, :, -1].mean((-2, -1)).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 64, 64)
         return output
 
-    def _evaluate_enqueue(self, pred, data):
-        """Device work of multi_evaluate (:317-427) on the CURRENT stream, no host read: roll the sampled controls through the PDE
-        solver and form the per-trajectory metric rows [B, 5] = (J_total, J_target, J_energy, mse, n_l2)."""
+    def _rollouts_enqueue(self, pred, data):
+        """First half of multi_evaluate's device work (:317-427) on the CURRENT stream, no host read: the sampled controls rolled through the
+        PDE solver (csrc/smoke_rollout.hip).  Returns what _metric_rows needs."""
         k = int(data.shape[-1] / pred.shape[-1])
         d00 = data[:, 0, 0].to(pred.device)          # (only the initial density is read: 1 MB instead of the batch's 1.6 GB)
         pred[:, 0, 0] = d00[:, ::k, ::k]
@@ -92,6 +96,12 @@ class InferencePipeline(object):
         pred_[:, :, 3:5, 8:56, 8:56] = 0                                         # indirect control (:330)
         dens, _, vel, smoke = solver_batch(self.sim, init_velocity_(), d00, pred_[:, :, 3], pred_[:, :, 4],
                                            per_timelength=256, frame_stride=8, space_stride=2, want_zero_density=False)
+        return pred, pred_, dens, vel, smoke
+
+    def _metric_rows(self, pred, pred_, dens, vel, smoke):
+        """Second half: the per-trajectory metric rows [B, 5] = (J_total, J_target, J_energy, mse, n_l2) -- torch element-wise kernels.  In
+        the overlapped schedule this runs on the sampling stream AFTER the side stream has drained, with nothing else resident: torch's own
+        kernels are built with packed fp32 instructions, which must not run beside another kernel."""
         B = pred.shape[0]
         cur = torch.empty(B, 32, 6, 64, 64, dtype=torch.float64, device=pred.device)     # data_current (:388-390)
         cur[:, :, 0] = dens
@@ -103,13 +113,16 @@ class InferencePipeline(object):
         p, d = pred * mask, cur * mask
         diff = p - d
         # (diff[:, :, -1:] and not the reference's diff[:, :, [-1]]: a list index becomes an index tensor that is copied to the device with a
-        #  BLOCKING copy on this stream -- the host then waits for the rollouts in front of it; same elements, same order)
+        #  BLOCKING copy on this stream -- the host then waits for whatever is queued in front of it; same elements, same order)
         mse = torch.cat((diff[:, :, :3], diff[:, :, -1:]), dim=2).square().mean((1, 2, 3, 4))
         n_l2 = diff[:, :, :3].square().sum((1, 2, 3, 4)).sqrt() / d[:, :, :3].square().sum((1, 2, 3, 4)).sqrt()
         J_target = -d[:, -1, -1, 0, 0]
         J_energy = d[:, :, 3:5].square().mean((1, 2, 3, 4))
         J_total = J_target + self.args_general.w_energy * J_energy
         return torch.stack((J_total, J_target, J_energy, mse, n_l2), dim=1)          # [B, 5] per-trajectory metric rows
+
+    def _evaluate_enqueue(self, pred, data):
+        return self._metric_rows(*self._rollouts_enqueue(pred, data))
 
     def _evaluate_report(self, rows, start):
         """The host side of multi_evaluate: ONE read of the batch means, the reference's print lines."""
@@ -136,9 +149,10 @@ class InferencePipeline(object):
         rows = []
         overlap = bool(getattr(self.args_general, "overlap_evaluator", True)) and len(dataloader) > 1
         side = torch.cuda.Stream(device=self.device) if overlap else None
+        self._side_stream = side
         budget = int(os.environ.get("DPC_EVALUATOR_CU_BUDGET", "192"))
         L = _lib.lib()
-        pending = None                      # (rows on the side stream, start time, tensors the side stream still reads)
+        pending = None                      # (rollout outputs on the side stream, start time, pred, the rollouts' completion event)
         tlog = os.environ.get("DPC_PIPELINE_LOG") == "1"
         t_run0 = time.time()
 
@@ -158,10 +172,10 @@ class InferencePipeline(object):
                 self.model[0].step_callback = None
 
         def finish(pend):
-            side.synchronize()
+            side.synchronize()               # the rollouts are done; the sampling stream is idle too (sample() ends with a host read)
             L.dpc_set_cu_budget(0)
             self.model[0].step_callback = None
-            out = self._evaluate_report(pend[0], pend[1])
+            out = self._evaluate_report(self._metric_rows(*pend[0]), pend[1])
             rows.append(self.last_rows)
             for key, v in zip(J, out):
                 J[key].append(v)
@@ -189,7 +203,7 @@ class InferencePipeline(object):
             start = time.time()
             with torch.cuda.stream(side):
                 side.wait_event(done)
-                r = self._evaluate_enqueue(pred, state)
+                r = self._rollouts_enqueue(pred, state)
                 rolled = torch.cuda.Event()
                 rolled.record()              # on the side stream: the rollouts (and the metric rows) are complete
             note(f"batch {i}: evaluator enqueued on the side stream")
