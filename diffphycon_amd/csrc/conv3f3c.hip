@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
             }
             bool scaled = false;                          // true: hreg already carries the operand pre-scale sa
             if (KD == 1) {
-                if (p.in_coef && cok) {
+                if (p.in_coef && cok && !(p.dbg & 64)) {
                     // per-image folded coefficients (second table of launch_gn_finalize_fused, "batch" = the F images of this launch)
                     const float cl = 1.4426950408889634f / sa;
                     const f32x4* tab = reinterpret_cast<const f32x4*>(p.in_coef + (long long)p.F * K * 5);
@@ -186,6 +186,23 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
                         hreg[i] = y;
                     }
                 }
+            }
+            if (p.dbg & 64) {
+                // perf attribution only (DPC_ENABLE_CONV_DBG builds, results INVALID): the loader keeps its loads and LDS writes but does no
+                // activation / pre-scale / split -- the raw bits, masked to finite fp16 patterns, go to LDS: what a loader that only COPIES
+                // pre-split planes would cost, with live operands for the MFMA stream (as conv3w.hip's bit 64)
+#pragma unroll
+                for (int i = 0; i < NITEM; ++i) {
+                    if ((hvalid >> i) & 1) {
+                        uint2 p1, p2;
+                        p1.x = __builtin_bit_cast(unsigned, hreg[i].x) & 0x3bff3bffu; p1.y = __builtin_bit_cast(unsigned, hreg[i].y) & 0x3bff3bffu;
+                        p2.x = __builtin_bit_cast(unsigned, hreg[i].z) & 0x3bff3bffu; p2.y = __builtin_bit_cast(unsigned, hreg[i].w) & 0x3bff3bffu;
+                        const int d = hdst[i] + boff;
+                        *reinterpret_cast<uint2*>(halo + d) = p1;
+                        *reinterpret_cast<uint2*>(halo + (d ^ 32)) = p2;
+                    }
+                }
+                return;
             }
 #pragma unroll
             for (int i = 0; i < NITEM; ++i) {
