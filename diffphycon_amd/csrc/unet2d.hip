@@ -205,7 +205,8 @@ struct Runner2D {
             float* part = ar.allocf((long long)mb * ent * Cout * 2);
             float* stats = ar.allocf((long long)mb * Cout * 2);
             float* coef = ar.allocf((long long)mb * Cout * 7);
-            float* raw2 = (same && dst == x0) ? ar.allocf(P * Cout) : dst;
+            float* raw2 = (same && dst == x0) ? ar.allocf(P * Cout) : dst;        // (not same: the fused res_conv epilogue reads raw2[i] and writes
+                                                                                  //  dst[i] element for element -- in place is fine, as in the 3-D net)
             if (c1 && c2) {
                 RUN(run_conv(*c1, x0, x1, C0, C1, raw(p + ".block1.proj.bias"), nullptr, raw1, mb, 1, Hl, Wl, Hl, Wl, nullptr, nullptr, 0, 0, 0,
                              s, part, nullptr));
@@ -213,11 +214,23 @@ struct Runner2D {
                                              ss, stats, coef, s, ent));
                 RUN(run_conv(*c2, raw1, nullptr, Cout, 0, raw(p + ".block2.proj.bias"), nullptr, raw2, mb, 1, Hl, Wl, Hl, Wl, nullptr, nullptr, 0,
                              0, 0, s, part, coef));
-                RUN(launch_gn_finalize_fused(part, mb, 0, Cout, h->cfg.groups, R, nullptr, nullptr, nullptr, stats, nullptr, s, ent));
-                RUN(launch_gn_apply(raw2, dst, same ? x0 : nullptr, stats, raw(p + ".block2.norm.weight"), raw(p + ".block2.norm.bias"), nullptr,
-                                    mb, R, Cout, h->cfg.groups, s));
-                if (!same)
-                    convolve(p + ".res_conv.weight", p + ".res_conv.bias", x0, x1, C0, C1, dst, dst, Hl, Wl, Hl, Wl, nullptr, nullptr, 0);
+                // block2's GroupNorm + SiLU: a streaming pass with the identity residual, or -- when the block has a res_conv (the up path's
+                // concatenated inputs) -- folded into the res_conv's epilogue as in the 3-D net (block2(h) + res_conv(x) without materialising
+                // block2's activated output; per-IMAGE coefficients: rows per sample = H W)
+                const PackedConv* rcv = same ? nullptr : conv(p + ".res_conv.weight");
+                const bool fuse_res = rcv && !dry() && conv_can_fuse_gn_residual(*rcv, R);
+                if (fuse_res) {
+                    RUN(launch_gn_finalize_fused(part, mb, 0, Cout, h->cfg.groups, R, raw(p + ".block2.norm.weight"), raw(p + ".block2.norm.bias"),
+                                                 nullptr, stats, coef, s, ent));
+                    RUN(run_conv(*rcv, x0, x1, C0, C1, raw(p + ".res_conv.bias"), nullptr, dst, mb, 1, Hl, Wl, Hl, Wl, nullptr, nullptr, 0, 0, 0, s,
+                                 nullptr, nullptr, raw2, coef));
+                } else {
+                    RUN(launch_gn_finalize_fused(part, mb, 0, Cout, h->cfg.groups, R, nullptr, nullptr, nullptr, stats, nullptr, s, ent));
+                    RUN(launch_gn_apply(raw2, dst, same ? x0 : nullptr, stats, raw(p + ".block2.norm.weight"), raw(p + ".block2.norm.bias"),
+                                        nullptr, mb, R, Cout, h->cfg.groups, s));
+                    if (!same)
+                        convolve(p + ".res_conv.weight", p + ".res_conv.bias", x0, x1, C0, C1, dst, dst, Hl, Wl, Hl, Wl, nullptr, nullptr, 0);
+                }
             }
             ar.release(m);
             return;
