@@ -742,7 +742,9 @@ class HipDesignGradient:
         self.p_min, self.p_max, self.reg_ratio = float(args.p_min), float(args.p_max), float(args.reg_ratio)
         self.calibrated = _MODE == "f16x3"            # per-convolution operand scales of the backward pass (_Calibration)
         self.check_every = int(os.environ.get("DPC_SURROGATE_RANGE_CHECK_EVERY", "64"))
+        self.watch_first = int(os.environ.get("DPC_SURROGATE_RANGE_WATCH_FIRST", "4"))
         self.calls = 0
+        self.since_check = 0                          # design-gradient calls since the last check_range()
         self.last_calibration = None                  # [(max |input| on the synthetic input, scale)] of the set-up pass
         self._calibrated_for = None                   # (T, Cd, H, W) the scales were fixed for
 
@@ -762,6 +764,7 @@ class HipDesignGradient:
 
     def check_range(self):
         """One host read per sample() call: did a backward tensor reach the fp16 clamp of its convolution since the last check?"""
+        self.since_check = 0
         convs = [c for c in (_Calibration.convs or ()) if getattr(c, "peak", None) is not None and c.act_scale > 0]
         if not convs:
             return None
@@ -784,8 +787,13 @@ class HipDesignGradient:
         B, T, Cd_, H, W = x.shape
         if self.calibrated and self._calibrated_for != (T, Cd_, H, W):
             self.calibrate(T, Cd_, H, W, x.device)
-        check = "watch" if (self.calibrated and self.check_every > 0 and self.calls % self.check_every == 0) else None
+        # device-side peak watch of the backward operands (no host read here; check_range() reads once per sample()): the first
+        # `watch_first` calls after every check -- the start of a chain is where a new input family would show -- and every
+        # `check_every`-th call after that (one call in 64 alone left the other 63 unwatched from the first step on)
+        check = "watch" if (self.calibrated and self.check_every > 0 and
+                            (self.since_check < self.watch_first or self.calls % self.check_every == 0)) else None
         self.calls += 1
+        self.since_check += 1
         per_traj = T * H * W * max(self.force.mid // 8, 64) * 4            # bytes of a level-0 activation per trajectory (dim = mid / 8)
         chunk = max(1, self._MAX_TENSOR_BYTES // per_traj)
         if B <= chunk:

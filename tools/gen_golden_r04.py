@@ -77,21 +77,37 @@ def full_extent_inputs(case):
     return cfg_kw, seed, x, torch.tensor(t)
 
 
+class _SamplingTaps(dict):
+    """The `taps` argument of oracle.unet3d_forward that keeps, per tap, only what the fixture records (shape, max |value|, the values at
+    `sample_index`'s positions) and drops the tensor at once: 36 taps of 268 MB each need not be resident together (the S128 cases spent
+    most of their time in page faults)."""
+
+    def __init__(self, seed):
+        super().__init__()
+        self.seed, self.rec = seed, {}
+
+    def __setitem__(self, name, r):
+        k = len(self.rec)
+        flat = r.contiguous().reshape(-1)
+        idx = sample_index(self.seed, k, flat.numel(), tuple(r.shape), 2 if name == "y" else 1)
+        self.rec[name] = (np.array(r.shape, dtype=np.int64), np.float32(flat.abs().max().item()),
+                          flat[torch.from_numpy(idx)].numpy().astype(np.float32))
+
+
 def full_extent_record(case):
     from oracle import unet3d as O
     cfg_kw, seed, x, tt = full_extent_inputs(case)
     cfg = O.Unet3DConfig(**cfg_kw)
     sd = O.synthetic_state_dict(cfg, seed=seed)
-    taps = {}
+    taps = _SamplingTaps(seed)
     with torch.no_grad():
         y = O.unet3d_forward(sd, cfg, x, tt, taps=taps)
-    out = {"names": np.array(list(taps) + ["y"])}
-    for k, (name, r) in enumerate(list(taps.items()) + [("y", y)]):
-        flat = r.contiguous().reshape(-1)
-        out[f"shape:{name}"] = np.array(r.shape, dtype=np.int64)
-        out[f"absmax:{name}"] = np.float32(flat.abs().max().item())
-        idx = sample_index(seed, k, flat.numel(), tuple(r.shape), 2 if name == "y" else 1)
-        out[f"values:{name}"] = flat[torch.from_numpy(idx)].numpy().astype(np.float32)
+    taps["y"] = y
+    out = {"names": np.array(list(taps.rec))}
+    for name, (shape, absmax, values) in taps.rec.items():
+        out[f"shape:{name}"] = shape
+        out[f"absmax:{name}"] = absmax
+        out[f"values:{name}"] = values
     return out
 
 
