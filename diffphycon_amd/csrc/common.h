@@ -127,6 +127,13 @@ struct OverflowScope {
 // cannot change which kernels run (the arithmetic modes DPC_*_MODE are the documented, per-handle-captured setting and are not
 // gated).  Switches that make a kernel skip work (DPC_CONV_DBG) exist only in builds with -DDPC_ENABLE_CONV_DBG.
 int debug_switch(const char* name, int dflt);
+// attribution bits added in r05 (Conv3hParams::dbg 8 / 64 / 128 / 256) exist in -DDPC_ENABLE_CONV_DBG builds only: the product kernels
+// do not even test them
+#ifdef DPC_ENABLE_CONV_DBG
+constexpr bool CONV_DBG_BUILD = true;
+#else
+constexpr bool CONV_DBG_BUILD = false;
+#endif
 int cu_budget(int ncu);           // api.hip: min(ncu, the value of dpc_set_cu_budget rounded down to a multiple of 8)
 // library-internal scratch buffer of at least `bytes` for (slot, current device, stream) -- api.hip; slots:
 enum { SCRATCH_SMALL_ACT = 0, SCRATCH_SPLITK = 1 };

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
             }
             bool scaled = false;                          // true: hreg already carries the operand pre-scale sa
             if (KD == 1) {
-                if (p.in_coef && cok && !(p.dbg & 64)) {
+                if (p.in_coef && cok && !(CONV_DBG_BUILD && (p.dbg & 64))) {
                     // per-image folded coefficients (second table of launch_gn_finalize_fused, "batch" = the F images of this launch)
                     const float cl = 1.4426950408889634f / sa;
                     const f32x4* tab = reinterpret_cast<const f32x4*>(p.in_coef + (long long)p.F * K * 5);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
                     }
                 }
             }
-            if (p.dbg & 64) {
+            if (CONV_DBG_BUILD && (p.dbg & 64)) {
                 // perf attribution only (DPC_ENABLE_CONV_DBG builds, results INVALID): the loader keeps its loads and LDS writes but does no
                 // activation / pre-scale / split -- the raw bits, masked to finite fp16 patterns, go to LDS: what a loader that only COPIES
                 // pre-split planes would cost, with live operands for the MFMA stream (as conv3w.hip's bit 64)
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv3f3c_kernel(Conv3hParams p) {
                             gs[4 * g + e] += v[e];
                             gq[4 * g + e] += v[e] * v[e];
                         }
-                        *reinterpret_cast<f32x4*>(base + 8 * g) = v;
+                        if (!(CONV_DBG_BUILD && (p.dbg & 8))) *reinterpret_cast<f32x4*>(base + 8 * g) = v;      // (bit 8: perf attribution -- no output stores)
                     }
                 }
                 float* gdst = nullptr;

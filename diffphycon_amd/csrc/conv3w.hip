@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         //       below: residual streams are O(1); the direct kernels' 2^4 bought 2^-29 at one more VALU op per element).  No clamp: |s V| > 65504 becomes inf and the output
         //       NaN / inf -- loud, never a silently clamped product (range check: dpc_unet3d_set_range_check).
         auto finish_item = [&](f32x4 (&d)[HFI], unsigned fok, int inflag, const f32x4& Ac, const f32x4& Bc, int dst0) {
-            if (p.dbg & 64) {             // attribution only: raw bits -> LDS (see the header), one v_and per dword
+            if (CONV_DBG_BUILD && (p.dbg & 64)) {             // attribution only: raw bits -> LDS (see the header), one v_and per dword
                 unsigned char* q0 = halo + dst0;
                 unsigned char* q1 = halo + (dst0 ^ 32);
 #pragma unroll
@@ -291,6 +291,10 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
                         asm("v_fma_mixlo_f16 %0, %1, %4, -%3 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %4, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
                             : "=&v"(p2.y) : "v"(v[k].z), "v"(v[k].w), "v"(p1.y), "s"(sc));
                     }
+                    // (perf attribution, DPC_ENABLE_CONV_DBG builds: 128 = the remainder plane of the activations is written as zeros, 256 = with
+                    //  its five low mantissa bits cleared -- how much of the launch time is the data-dependent power draw of the small-term MFMAs)
+                    if (CONV_DBG_BUILD && (p.dbg & 128)) { p2.x = 0; p2.y = 0; }
+                    if (CONV_DBG_BUILD && (p.dbg & 256)) { p2.x &= 0xffe0ffe0u; p2.y &= 0xffe0ffe0u; }
                     *reinterpret_cast<uint2*>(q0 + (pr * 4 + k) * 6400) = p1;
                     *reinterpret_cast<uint2*>(q1 + (pr * 4 + k) * 6400) = p2;
                     if (GN && (k & 1)) __builtin_amdgcn_sched_barrier(0);     // (register budget of the fused-activation variant)
