@@ -105,3 +105,26 @@ def test_s128_prior_fixture_is_what_the_oracle_computes():
         assert len(g[f"values:{name}"]) == min(G.NSAMP, int(np.prod(shape))) + n_edge and (n_edge > 4000 or len(shape) != 5)
         scale = float(g[f"absmax:{name}"])
         assert np.abs(rec[f"values:{name}"] - g[f"values:{name}"]).max() <= 2e-6 * scale, name
+
+
+def test_edge_index_touches_every_tile_and_every_seam():
+    """tools/gen_golden_r04.edge_index (the deterministic positions of the full-extent fixtures): along each of the frame / row / column
+    axes the lines cross EVERY 4 x 8 x 8 output tile of the tensor and both sides of every seam between two tiles, for taps
+    [1, C, F, H, W] and for the output layout [1, F, C, H, W]; positions are unique and inside the tensor."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_golden_r04 as G
+    for shape, ax in (((1, 64, 32, 64, 64), 1), ((1, 128, 64, 32, 32), 1), ((1, 256, 20, 16, 16), 1), ((1, 32, 6, 64, 64), 2)):
+        idx = G.edge_index(shape, ax)
+        assert len(idx) == len(set(idx.tolist())) and idx.min() >= 0 and idx.max() < int(np.prod(shape))
+        c, f, h, w = np.unravel_index(idx, shape)[1:] if ax == 1 else [np.unravel_index(idx, shape)[i] for i in (2, 1, 3, 4)]
+        C_, F_, H_, W_ = (shape[1], shape[2], shape[3], shape[4]) if ax == 1 else (shape[2], shape[1], shape[3], shape[4])
+        assert set(c.tolist()) == {0, C_ // 2, C_ - 1}
+        tiles = {(ff // 4, hh // 8, ww // 8) for ff, hh, ww in zip(f.tolist(), h.tolist(), w.tolist())}
+        # every tile index occurs along each axis (a line along an axis visits all tiles of that axis) ...
+        assert {t[0] for t in tiles} == set(range((F_ + 3) // 4)) and {t[1] for t in tiles} == set(range(H_ // 8)) and {t[2] for t in tiles} == set(range(W_ // 8))
+        # ... and so do both sides of every seam (last point of a tile, first point of the next)
+        assert set(range(F_)) <= set(f.tolist()) and set(range(H_)) <= set(h.tolist()) and set(range(W_)) <= set(w.tolist())
+    assert len(G.edge_index((1, 256), 1)) == 0
+    assert len(G.sample_index(41, 3, 8388608, (1, 64, 32, 64, 64), 1)) == G.NSAMP + len(G.edge_index((1, 64, 32, 64, 64), 1))
