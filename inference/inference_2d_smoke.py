@@ -180,39 +180,44 @@ class InferencePipeline(object):
             for key, v in zip(J, out):
                 J[key].append(v)
 
-        for i, (state, sim_id) in enumerate(dataloader):
-            print(f"Batch No.{i}")
-            note(f"batch {i}: loader returned")
-            ids = [int(v) for v in sim_id]
-            assert ids == list(range(ids[0], ids[0] + len(ids))), "batches must hold consecutive simulation ids"
-            # noise keyed by the global simulation id (Philox): independent of batch size and of the sharding over ranks
-            self.model[0].traj_offset, self.model[0].noise_epoch = ids[0], 0
-            pred = self.run_model(state)
-            note(f"batch {i}: run_model returned")
-            print("pred shape: ", pred.shape)
-            if not overlap:
-                out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
-                rows.append(self.last_rows)
-                for key, v in zip(J, out):
-                    J[key].append(v)
-                continue
+        try:
+            for i, (state, sim_id) in enumerate(dataloader):
+                print(f"Batch No.{i}")
+                note(f"batch {i}: loader returned")
+                ids = [int(v) for v in sim_id]
+                assert ids == list(range(ids[0], ids[0] + len(ids))), "batches must hold consecutive simulation ids"
+                # noise keyed by the global simulation id (Philox): independent of batch size and of the sharding over ranks
+                self.model[0].traj_offset, self.model[0].noise_epoch = ids[0], 0
+                pred = self.run_model(state)
+                note(f"batch {i}: run_model returned")
+                print("pred shape: ", pred.shape)
+                if not overlap:
+                    out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
+                    rows.append(self.last_rows)
+                    for key, v in zip(J, out):
+                        J[key].append(v)
+                    continue
+                if pending is not None:
+                    finish(pending)              # batch i - 1's rollouts ran beside this batch's sampling
+                done = torch.cuda.Event()
+                done.record()                    # pred is complete on the sampling stream
+                start = time.time()
+                with torch.cuda.stream(side):
+                    side.wait_event(done)
+                    r = self._rollouts_enqueue(pred, state)
+                    rolled = torch.cuda.Event()
+                    rolled.record()              # on the side stream: the rollouts (and the metric rows) are complete
+                note(f"batch {i}: evaluator enqueued on the side stream")
+                pending = (r, start, pred, rolled)
+                if budget > 0:
+                    L.dpc_set_cu_budget(budget)  # the next batch's persistent kernels leave the rollouts' CUs alone ...
+                    self.model[0].step_callback = release_budget          # ... until the rollouts are done
             if pending is not None:
-                finish(pending)              # batch i - 1's rollouts ran beside this batch's sampling
-            done = torch.cuda.Event()
-            done.record()                    # pred is complete on the sampling stream
-            start = time.time()
-            with torch.cuda.stream(side):
-                side.wait_event(done)
-                r = self._rollouts_enqueue(pred, state)
-                rolled = torch.cuda.Event()
-                rolled.record()              # on the side stream: the rollouts (and the metric rows) are complete
-            note(f"batch {i}: evaluator enqueued on the side stream")
-            pending = (r, start, pred, rolled)
-            if budget > 0:
-                L.dpc_set_cu_budget(budget)  # the next batch's persistent kernels leave the rollouts' CUs alone ...
-                self.model[0].step_callback = release_budget          # ... until the rollouts are done
-        if pending is not None:
-            finish(pending)
+                finish(pending)
+        finally:
+            # (an exception inside the loop must not leave the library's process-wide CU budget lowered or the sampler's hook installed)
+            L.dpc_set_cu_budget(0)
+            self.model[0].step_callback = None
         if getattr(self.args_general, "world_size", 1) > 1:
             # one RCCL all_gather pair for the whole run (variable row counts per rank, global trajectory order); the summary
             # is then the mean over ALL trajectories (= the reference's mean of batch means when batches are equal-sized)
