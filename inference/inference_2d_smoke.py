@@ -206,7 +206,7 @@ class InferencePipeline(object):
                     side.wait_event(done)
                     r = self._rollouts_enqueue(pred, state)
                     rolled = torch.cuda.Event()
-                    rolled.record()              # on the side stream: the rollouts (and the metric rows) are complete
+                    rolled.record()              # on the side stream: the rollouts are complete (the metric rows follow in finish())
                 note(f"batch {i}: evaluator enqueued on the side stream")
                 pending = (r, start, pred, rolled)
                 if budget > 0:
