@@ -27,7 +27,7 @@ SRC_FLAGS = {"tattn3.hip": ["-ffp-contract=fast"], "lattn3.hip": ["-ffp-contract
 # Kernels that must compile WITHOUT register spills: a spilling build of the 128-register implicit-GEMM kernel has (twice) given
 # batch-size dependent results at full size; the build fails instead of shipping one.
 # conv3w_kernel: its loader waves count their own vmcnt -- a compiler-inserted scratch reload there waits for every load in flight.
-NO_SPILL = {"igemm6.hip": ("igemm3_kernel",), "conv3w.hip": ("conv3w_kernel",), "igemm_wide.hip": ("igemm3w_kernel",),
+NO_SPILL = {"igemm6.hip": ("igemm3_kernel",), "conv3w.hip": ("conv3w_kernel",), "conv3w4.hip": ("conv3w4_kernel",), "conv3f3c.hip": ("conv3f3c_kernel",), "igemm_wide.hip": ("igemm3w_kernel",),
             "igemm_panel.hip": ("igemm3p_kernel",), "igemm_tile.hip": ("igemm3t_kernel",), "stem7x6.hip": ("stem7p_kernel",), "igemm_img.hip": ("igemm3i_kernel",)}
 
 

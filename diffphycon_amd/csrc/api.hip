@@ -156,7 +156,7 @@ const char* dpc_get_mode(const char* family) {
     return buf.c_str();
 }
 
-const char* dpc_conv3d_algorithm(void) { return conv3w_shape_ok(4, 8, 8, 64, 64) ? "winograd_f23_frames" : "direct"; }
+const char* dpc_conv3d_algorithm(void) { return !conv3w_shape_ok(4, 8, 8, 64, 64) ? "direct" : conv3w_f43_enabled() ? "winograd_f43_frames" : "winograd_f23_frames"; }
 
 int dpc_ddpm_update_smoke(const float* x, const float* eps_j, const float* eps_w, const float* z, const float* init,
                           const float* rescaler, float* x_next, float* x0_out, const dpc_step_coef* coef, int B,
@@ -201,8 +201,9 @@ int dpc_philox_normal(float* out, int B, int64_t per_traj, uint64_t seed, int64_
 }
 
 size_t dpc_conv_workspace_bytes(int Cin, int Cout, int ntaps) {
-    // room for the fp32 pack (128 B per (n, 32-channel chunk, tap)) or the bf16x6 pack (192 B)
-    return (size_t)ntaps * igemm_kchunks(Cin) * igemm_npad(Cout) * 192 + 256;
+    // room for the fp32 pack (128 B per (n, 32-channel chunk, tap)), the bf16x6 pack (192 B) or the Winograd F(4,3) pack of a 27-tap
+    // convolution (54 x 128 B per (n, 32-channel chunk) = 256 B per tap)
+    return (size_t)ntaps * igemm_kchunks(Cin) * igemm_npad(Cout) * 256 + 256;
 }
 
 int dpc_conv3d_cl(const float* x_cl, const float* w_ref, const float* bias, float* out_cl, int B, int F, int H, int W,

@@ -360,6 +360,12 @@ bool conv3w_supported(const Conv3hParams& p);
 long long conv3w_gn_entries(int F, int H, int W);
 int launch_conv3w(const Conv3hParams& p, hipStream_t s);
 size_t conv3w_packed_bytes(int Npad, int K);
+// Winograd F(4,3)-over-frames form (conv3w4.hip, r06): 3/4 of conv3w's matrix products.  Default; launch_conv3w / launch_pack_weights_w3 /
+// conv3w_packed_bytes forward to it (same shape rule, same GroupNorm partial-sum entry count), DPC_DEBUG=1 DPC_CONV3W_F43=0 keeps F(2,3).
+bool conv3w_f43_enabled();
+int launch_conv3w4(const Conv3hParams& p, hipStream_t s);
+size_t conv3w4_packed_bytes(int Npad, int K);
+int launch_pack_weights_w4(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
 int launch_pack_weights_w3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s);
 // 0: native fp32 MFMA (conv3h), 1: bf16x6 split (conv3x6), 2: f16x3 split (conv3f3); env DPC_CONV_MODE=f32|x6|f16x3, default f16x3
 int conv_mode_default();

@@ -486,6 +486,18 @@ __global__ __launch_bounds__(512, 2) void conv3w_kernel(Conv3hParams p) {
         } else {
             wnext += wtap;
         }
+        if (CONV_DBG_BUILD && (p.dbg & 1024)) {           // attribution only (r06; results INVALID): every weight fragment is requested TWICE,
+                                                          // the second time from the neighbour component's stream as an LDS-DMA into the unused
+                                                          // tail of halo buffer 0 (no destination registers) -- the L2 -> L1 weight traffic per
+                                                          // MFMA of an F(4,3) form whose register budget halves the fragment reuse
+            const unsigned char* s2 = src + (long long)((((wave + 1) & 3) - wave) * NTAPS) * wtap;
+            const int m0v = 52 * 1024 + wave * 1024;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(s2 + nt * 32 * WROW + pl * 32), "s"(m0v) : "memory", "m0");
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -619,6 +631,7 @@ long long conv3w_gn_entries(int F, int H, int W) { return (long long)((F + 3) / 
 
 int launch_conv3w(const Conv3hParams& p, hipStream_t s) {
     using namespace f3c;
+    if (conv3w_f43_enabled()) return launch_conv3w4(p, s);      // F(4,3) form (conv3w4.hip): the pack in p.wpw is then its 6-component one
     const long long tiles = (long long)p.B * ((p.F + 3) / 4) * (p.H / 8) * (p.W / 8);
     const long long nwg = tiles * (p.Npad / 64);
     DPC_REQUIRE(nwg < (1ll << 31), "conv3w: too many tiles");
@@ -682,9 +695,13 @@ __global__ void pack_weights_w3_kernel(const float* __restrict__ w, unsigned sho
     }
 }
 
-size_t conv3w_packed_bytes(int Npad, int K) { return (size_t)36 * ((K + 15) / 16) * Npad * 64; }
+size_t conv3w_packed_bytes(int Npad, int K) {
+    return conv3w_f43_enabled() ? conv3w4_packed_bytes(Npad, K) : (size_t)36 * ((K + 15) / 16) * Npad * 64;
+}
 
+// (the pack follows the form launch_conv3w will run: one process-wide switch decides both)
 int launch_pack_weights_w3(const float* w, void* wp, int N, int Npad, int K, hipStream_t s) {
+    if (conv3w_f43_enabled()) return launch_pack_weights_w4(w, wp, N, Npad, K, s);
     const int kchunks = (K + 15) / 16;
     const long long total = (long long)36 * kchunks * Npad * 16;
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);

@@ -23,7 +23,7 @@ CSRC = os.path.join(ROOT, "diffphycon_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang",
          "-packed-fp32-ops", "-S", "--cuda-device-only"]          # (= diffphycon_amd/build.py FLAGS)
 LOOKBACK = 12
-DEFAULT = ["conv3w.hip", "conv3f3c.hip", "igemm6.hip", "igemm_panel.hip", "igemm_tile.hip", "igemm_wide.hip", "igemm_img.hip", "stem7x6.hip", "tattn3.hip",
+DEFAULT = ["conv3w4.hip", "conv3w.hip", "conv3f3c.hip", "igemm6.hip", "igemm_panel.hip", "igemm_tile.hip", "igemm_wide.hip", "igemm_img.hip", "stem7x6.hip", "tattn3.hip",
            "lattn3.hip", "wgrad3.hip", "attn.hip", "surr.hip", "train.hip", "unet2d.hip"]
 
 REG = re.compile(r"\b([va])(?:\[(\d+):(\d+)\]|(\d+)\b)")

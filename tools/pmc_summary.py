@@ -19,7 +19,7 @@ from collections import defaultdict
 # kernel symbol -> bench.py / ProfScope class name
 CLASSES = [
     (r"conv3(x6|f3[bc]?)_kernel<128", "conv3x6_bn128"), (r"conv3(x6|f3[bc]?)_kernel<64", "conv3x6_bn64"),
-    (r"conv3w_kernel<(true|false), 128>", "conv3x6_bn128"), (r"conv3w_kernel<(true|false), 64>", "conv3x6_bn64"),
+    (r"conv3w4?_kernel<(true|false), 128>", "conv3x6_bn128"), (r"conv3w4?_kernel<(true|false), 64>", "conv3x6_bn64"),
     (r"conv3h_kernel<128", "conv3h_bn128"), (r"conv3h_kernel<64", "conv3h_bn64"),
     (r"igemm3p_kernel<\d+, 1, 1, 2, 2", "igemm_bn64"), (r"igemm3p_kernel<", "igemm_bn128"),       # (row panels: N = 32 NT WN)
     (r"igemm3w_kernel<(true|false), 64>", "igemm_bn64"), (r"igemm3w_kernel<", "igemm_bn128"),
@@ -38,7 +38,7 @@ CLASSES = [
 # profile class -> the kernel source file(s) whose code its default-mode launches run: the traffic numbers are stamped with a hash
 # of these files and bench.py reports `traffic: null` when the stamp no longer matches the tree (a changed kernel = stale counters)
 SOURCES = {
-    "conv3x6_bn64": ["conv3w.hip", "conv3f3c.hip"], "conv3x6_bn128": ["conv3w.hip", "conv3f3c.hip"], "igemm_bn64": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_img.hip", "igemm_epilogue.h"],
+    "conv3x6_bn64": ["conv3w4.hip", "conv3w.hip", "conv3f3c.hip"], "conv3x6_bn128": ["conv3w4.hip", "conv3w.hip", "conv3f3c.hip"], "igemm_bn64": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_img.hip", "igemm_epilogue.h"],
     "igemm_bn128": ["igemm6.hip", "igemm_panel.hip", "igemm_wide.hip", "igemm_tile.hip", "igemm_img.hip", "igemm_epilogue.h"], "stem_gather": ["stem7x6.hip"], "temporal_attention_fused": ["tattn3.hip"],
     "linear_attention_fused": ["lattn3.hip"], "groupnorm_silu": ["norm.hip"], "ln_stats": ["norm.hip"], "attention_core": ["attn.hip"],
     "ddpm_update": ["update.hip"], "conv3_wgrad_f16x3": ["wgrad3.hip"], "conv_wgrad": ["train.hip"], "attention_bwd": ["train.hip"],
