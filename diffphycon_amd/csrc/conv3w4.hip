@@ -30,7 +30,8 @@
 //     [6][9 taps][chunk][n][2 planes][16] fp16 (launch_pack_weights_w4), two running pointers, 3-deep register ring.
 //     Fragment re-loads keep conv3w's rule (a set is re-loaded >= 4 MFMAs after its last reader was issued and 8 MFMAs before its
 //     next reader: DESIGN.md 6.2, third hazard): three sets -- component A rows 0-3, rows 4-7, component B -- rotate through the
-//     three 6-MFMA groups of a tap.
+//     three 6-MFMA groups of a tap.  (Measured and dropped, profiles/r06_e_term_major_ab.log: all four sets double-buffered and the
+//     18 MFMAs of a tap in term-major order over the six tiles -- an accumulator revisited after 6 instead of 2 MFMAs -- is 11 % SLOWER.)
 //   * Epilogue: ONE exchange per tile (conv3w: one per frame pair).  The four MFMA waves park all six components in LDS (96 KB: halo
 //     buffer 1, which every tile leaves last, and the otherwise unused tail), the loader waves read them between two barriers --
 //     wave l takes plane rows 2l, 2l+1 of all four output frames and both channel halves: 6 reads per 4 output values -- combine,
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
                     if (term == 2) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
+                        mfma_keep(accA[0][0], aB[0][0], aB[0][1], aB[1][0], aB[1][1]);      // (spent B operands keep their registers up to here)
                         lda(aB[0], aaddr[tap] + (boff + offB), 0);
                         lda(aB[1], aaddr[tap] + (boff + offB), 1);
                         asm volatile("" ::: "memory");
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
                     if (term == 2) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
+                        mfma_keep(accA[1][0], aA[0][0], aA[0][1]);
                         if (tap < NTAPS - 1) lda(aA[0], aaddr[tap + 1 < NTAPS ? tap + 1 : tap] + boff, 0);
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
                     if (term == 2) {
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
+                        mfma_keep(accB[0], aA[1][0], aA[1][1]);
                         if (tap < NTAPS - 1) lda(aA[1], aaddr[tap + 1 < NTAPS ? tap + 1 : tap] + boff, 1);
                         asm volatile("" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
@@ -550,8 +554,11 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
             };
 #pragma unroll
             for (int tap = 0; tap < NTAPS; ++tap) tap_body(tap);
-            // MFMA B-operand guard (see igemm6.hip): nothing may overwrite the activation fragments while the last MFMA reads them
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            // MFMA B-operand guard (third hazard): the next chunk's first fragment loads may be given the registers of the
+            // fragments the last MFMAs read (hipcc re-uses them: tools/mfma_war_audit.py) -- the wave waits for the last MFMA of both
+            // component-B chains (the youngest six MFMAs of the chunk) before it enters the barrier
+            mfma_drain(accB[0]);
+            mfma_drain(accB[1]);
             __builtin_amdgcn_sched_barrier(0);
             wg_barrier();                                  // next chunk's buffer is complete; this one may be overwritten
             boff = HB1 - boff;

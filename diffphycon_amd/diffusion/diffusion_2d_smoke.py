@@ -468,9 +468,21 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ checkpoints (:942-985)
     def _param_order(self):
-        """(flat-buffer key, shape) in the order of `diffusion_model.parameters()` -- the index space of torch.optim.Adam's
-        state_dict (:912: Adam(diffusion_model.parameters())); the denoiser is the diffusion's only parameterised child."""
-        return [(k, tuple(p.shape)) for k, p in self.model.model.named_parameters()]
+        """(flat-buffer key | None, shape) in the order of the REFERENCE's `diffusion_model.parameters()` -- the index space of
+        torch.optim.Adam's state_dict (:912: Adam(diffusion_model.parameters())); the denoiser is the diffusion's only parameterised
+        child.  Two things differ from this package's own registration order (pinned by tests/test_checkpoint_layout.py on a
+        checkpoint built from the imported reference): the reference registers `ups` right after `downs`, BEFORE the mid blocks
+        (video_diffusion_pytorch_conv3d.py: both ModuleLists are created before `mid_block1`), and its shared RotaryEmbedding's
+        `freqs` is an nn.Parameter (requires_grad False), listed once where it is first met -- inside `init_temporal_attn`, before
+        `to_qkv`.  That slot is kept as (None, shape): it owns an index, never a gradient, so Adam holds no state for it."""
+        named = [(k, tuple(p.shape)) for k, p in self.model.model.named_parameters()]
+        rank = {"time_rel_pos_bias": 0, "init_conv": 1, "init_temporal_attn": 2, "time_mlp": 3, "downs": 4, "ups": 5, "mid_block1": 6,
+                "mid_spatial_attn": 7, "mid_temporal_attn": 8, "mid_block2": 9, "final_conv": 10}
+        order = sorted(enumerate(named), key=lambda it: (rank[it[1][0].split(".")[0]], it[0]))        # stable inside a prefix
+        out = [kv for _, kv in order]
+        at = next(i for i, (k, _) in enumerate(out) if k.startswith("init_temporal_attn."))
+        out.insert(at, (None, (min(32, getattr(self.model.model, "attn_dim_head", 32)) // 2,)))
+        return out
 
     def load(self, milestone):
         """(:957-985) model weights, step, optimizer state and EMA.  `opt` is torch.optim.Adam's state_dict ({'state': {i: {'step',
@@ -506,10 +518,14 @@ class Trainer(object):
         T = self._t
         order = self._param_order()
         if opt is not None and opt["state"]:
-            if len(opt["state"]) != len(order):
-                raise ValueError(f"checkpoint optimizer state holds {len(opt['state'])} parameters, the denoiser has {len(order)}")
+            n_state = sum(1 for k, _ in order if k is not None)
+            if any(i not in opt["state"] for i, (k, _) in enumerate(order) if k is not None) or len(opt["state"]) > len(order):
+                raise ValueError(f"checkpoint optimizer state holds {len(opt['state'])} parameters (indices {min(opt['state'])}..{max(opt['state'])}), "
+                                 f"the denoiser has {n_state} trainable ones in {len(order)} slots")
             steps = set()
             for i, (k, shape) in enumerate(order):
+                if k is None:
+                    continue                         # (the rotary table's slot: no gradient, no state -- or a stale one; never applied)
                 st = opt["state"][i]
                 if tuple(st["exp_avg"].shape) != shape:
                     raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {k} has {shape}")
@@ -522,6 +538,8 @@ class Trainer(object):
             self.opt_step = steps.pop()              # Adam's bias correction AND MultiStepLR's position (one scheduler step per optimizer step)
         if ema is not None:
             for k, _ in order:
+                if k is None:
+                    continue
                 o, n = T.offsets[k], T.ctx.W[k].numel()
                 self.ema[o:o + n].copy_(ema["ema_model.model." + k].reshape(-1).to(self.ema.device, torch.float32))
             self.ema_sched.step, self.ema_sched.initted = int(ema["step"]), bool(ema["initted"])
@@ -536,10 +554,11 @@ class Trainer(object):
             T, order = self._t, self._param_order()
 
             def views(flat):
-                return {k: flat[T.offsets[k]:T.offsets[k] + T.ctx.W[k].numel()].view(shape).cpu().clone() for k, shape in order}
+                return {k: flat[T.offsets[k]:T.offsets[k] + T.ctx.W[k].numel()].view(shape).cpu().clone() for k, shape in order if k is not None}
             m, v = views(self.m), views(self.v)
+            # (index = position in the reference's parameters(); the rotary table's slot holds no state, as in a reference file)
             opt = {"state": {i: {"step": torch.tensor(float(self.opt_step)), "exp_avg": m[k], "exp_avg_sq": v[k]}
-                             for i, (k, _) in enumerate(order)} if self.opt_step > 0 else {},
+                             for i, (k, _) in enumerate(order) if k is not None} if self.opt_step > 0 else {},
                    "param_groups": [{"lr": self._lr(), "betas": self.adam_betas, "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
                                      "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                                      "initial_lr": self.train_lr, "params": list(range(len(order)))}]}

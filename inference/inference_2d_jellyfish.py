@@ -183,6 +183,12 @@ def build_parser():
     p.add_argument("--sampling_timesteps", default=1000, type=int)
     p.add_argument("--image_size", type=int, default=64)
     p.add_argument("--inference_result_path", default="./results_jellyfish/", type=str)
+    # the two flags the reference's DDPM branch also takes (inference_2d_jellyfish.py:916-919): results are written under
+    # --inference_result_subpath (reference :835; there it is always re-derived as <inference_result_path>/<timestamp>_coeff_ratio_w_.._J.._ ,
+    # :956-959 -- here an explicit value is honoured and the default is the result path itself, so reruns overwrite instead of piling up);
+    # --log_path is the Trainer's log folder (reference :167), only created here: sampling writes no training logs
+    p.add_argument("--inference_result_subpath", default=None, type=str)
+    p.add_argument("--log_path", default=None, type=str)
     p.add_argument("--design_guidance", default="standard-alpha", type=str)
     p.add_argument("--inference_method", default="DDPM", type=str)
     p.add_argument("--force_model_checkpoint", type=str,
@@ -213,7 +219,11 @@ if __name__ == "__main__":
         # fail before any checkpoint is read
         raise FileNotFoundError(f"no Jellyfish test split under {args.dataset_path}/test_data; mount it or pass --synthetic True")
     load_normalization(args)
+    if args.inference_result_subpath is None:
+        args.inference_result_subpath = args.inference_result_path
+    if args.log_path and args.rank == 0:
+        os.makedirs(args.log_path, exist_ok=True)
     force_model, diffusion, bd_updater, design_fn = load_model(args)
     ppl = InferencePipeline(diffusion, {"design_fn": design_fn, "design_guidance": args.design_guidance,
-                                        "bd_updater": bd_updater}, results_path=args.inference_result_path, args_general=args)
+                                        "bd_updater": bd_updater}, results_path=args.inference_result_subpath, args_general=args)
     ppl.run(synthetic_batches(args) if args.synthetic else dataset_batches(args))

@@ -68,10 +68,14 @@ def test_smoke_pipeline_evaluator_overlap_equals_the_serial_schedule(tmp_path):
 
 
 def test_jellyfish_inference_script(tmp_path):
+    """carries the reference's two path flags of the DDPM branch as well (inference_2d_jellyfish.py:916-919): results land under
+    --inference_result_subpath, --log_path is created"""
+    sub, logs = os.path.join(str(tmp_path), "sub"), os.path.join(str(tmp_path), "logs")
     out = run(["inference/inference_2d_jellyfish.py", "--synthetic", "True", "--batch_size", "1", "--num_batches", "1",
-               "--frames", "4", "--image_size", "64", "--timesteps", "3", "--inference_result_path", str(tmp_path)], ROOT)
+               "--frames", "4", "--image_size", "64", "--timesteps", "3", "--inference_result_path", str(tmp_path),
+               "--inference_result_subpath", sub, "--log_path", logs], ROOT)
     assert "Final results!" in out
-    assert os.path.exists(os.path.join(str(tmp_path), "thetas", "0.npy"))
+    assert os.path.exists(os.path.join(sub, "thetas", "0.npy")) and os.path.isdir(logs)
 
 
 # ------------------------------------------------------------------------------------------------ multi-rank (N > 1) path

@@ -229,7 +229,8 @@ def test_checkpoint_resume_is_bit_identical_to_the_uninterrupted_run(dev, tmp_pa
     first.save(7)
     ck = torch.load(str(tmp_path / "model-7.pt"), map_location="cpu")
     n = len(list(first.model.parameters()))
-    assert set(ck["opt"]) == {"state", "param_groups"} and len(ck["opt"]["state"]) == n and ck["opt"]["param_groups"][0]["params"] == list(range(n))
+    # (index space = the reference's parameters(): one more slot than trainable parameters -- its rotary table -- which holds no state)
+    assert set(ck["opt"]) == {"state", "param_groups"} and len(ck["opt"]["state"]) == n and ck["opt"]["param_groups"][0]["params"] == list(range(n + 1))
     assert {"initted", "step", "ema_model.model.init_conv.weight", "online_model.model.init_conv.weight", "ema_model.betas"} <= set(ck["ema"])
     resumed = _trainer(g, dev, results_path=str(tmp_path))
     resumed.load(7)                                  # no training buffers yet: the state is applied when they are built
@@ -249,6 +250,35 @@ def test_checkpoint_resume_is_bit_identical_to_the_uninterrupted_run(dev, tmp_pa
     torch.save(ck, str(tmp_path / "model-8.pt"))
     with pytest.raises(ValueError, match="Adam state_dict"):
         _trainer(g, dev, results_path=str(tmp_path)).load(8)
+
+
+def test_resume_from_a_checkpoint_in_the_reference_layout(dev):
+    """tests/golden/ckpt_smoke/model-1.pt: the imported reference's GaussianDiffusion.state_dict() + a real torch.optim.Adam.state_dict()
+    over ITS parameters() (tools/gen_golden_r06.py; CPU side of the same file: tests/test_checkpoint_layout.py).  Trainer.load() + the
+    first use of the training buffers must put the moment stored at the reference's index i into the flat buffer of the parameter that
+    owns index i there: the generator's first moment is 1e-4 (1 + i) everywhere in parameter i."""
+    import os
+    from conftest import GOLDEN
+    from diffphycon_amd.diffusion.diffusion_2d_smoke import GaussianDiffusion, Trainer
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    m = Unet3D_with_Conv3D(dim=8, dim_mults=(1, 2), channels=6)
+    gd = GaussianDiffusion(m, image_size=16, frames=4, timesteps=1000, sampling_timesteps=100, loss_type="l2", objective="pred_noise", device=dev)
+    tr = Trainer(gd, "Smoke", None, train_batch_size=2, results_path=os.path.join(GOLDEN, "ckpt_smoke"), bwd_mode="x6")
+    tr.load(1)
+    T = tr._ensure()                                  # builds the flat buffers and applies the pending optimizer / EMA state
+    ck = torch.load(os.path.join(GOLDEN, "ckpt_smoke", "model-1.pt"), map_location="cpu")
+    assert tr.opt_step == 1 and tr.step == 7
+    names = ck["_param_names"]
+    checked = 0
+    for i, name in enumerate(names):
+        if name.endswith("rotary_emb.freqs"):
+            continue
+        k = name[len("model."):]
+        o, n = T.offsets[k], T.ctx.W[k].numel()
+        assert torch.allclose(tr.m[o:o + n].cpu(), torch.full((n,), 1e-4 * (1 + i)), rtol=1e-5), (i, k)
+        assert torch.equal(tr.ema[o:o + n].cpu(), ck["ema"]["ema_model.model." + k].reshape(-1)), k
+        checked += 1
+    assert checked == len(names) - 1 == len(T.names)
 
 
 @pytest.mark.parametrize("bwd_mode,loss_scale", [("x6", 1.0), ("f16x3", 2.0 ** 20)])

@@ -66,6 +66,31 @@ def test_full_width_vs_oracle(mults, groups, B, dev):
     assert rel(y, ref) < 1e-4, rel(y, ref)
 
 
+def test_popc_width_matches_reference_fixture(dev):
+    """tests/golden/unet2d_popc.npz (tools/gen_golden_r06.py): the REFERENCE's Unet2D at the POPC joint width -- dim 64, mults
+    (1, 2, 4, 8, 16), one GroupNorm group (burgers_inference_partial_obs_partial_ctr.sh) -- on 2 x 2 x 16 x 128 with the seeded
+    synthetic weights (rebuilt here from the seed).  Until r06 this width was compared with the repo's oracle only."""
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from oracle import unet2d as U
+    g = load_golden("unet2d_popc")
+    mults = tuple(int(v) for v in g["dim_mults"])
+    cfg = U.Unet2DConfig(dim=64, dim_mults=mults, resnet_block_groups=1)
+    m = Unet2D(dim=64, out_dim=2, dim_mults=mults, channels=2, resnet_block_groups=1)
+    m.load_state_dict(U.synthetic_state_dict(cfg, seed=int(g["seed"])))
+    m = m.to(dev)
+    m.debug_taps(True)
+    y = m(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["t"]).to(dev)).cpu()
+    assert rel(y, torch.from_numpy(g["y"])) < 1e-4, rel(y, torch.from_numpy(g["y"]))
+    n = 0
+    for k in g.files:
+        if k.startswith("tap:"):
+            ref = torch.from_numpy(g[k])
+            got = m.get_tap(k[4:], tuple(ref.shape), dev).cpu()
+            assert rel(got, ref) < 1e-4, (k, rel(got, ref))
+            n += 1
+    assert n == 3
+
+
 def test_fused_linear_attention_equals_the_unfused_composition(dev, monkeypatch):
     """r04: at C = 64 / 128 the LinearAttention block (PreNorm LayerNorm -> qkv -> softmaxes -> context -> to_out -> LayerNorm -> + x,
     model/burgers_1d/unet.py:188-229) is ONE launch (lattn3.hip, OUT_LN form).  DPC_UNFUSED_ATTN=1 (captured when the handle is

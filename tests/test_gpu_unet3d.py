@@ -74,6 +74,28 @@ def test_unet3d_matches_reference_fixture(tag, arithmetic, dev):
     assert err < OUT_TOL, err
 
 
+@pytest.mark.parametrize("arithmetic", ["f16x3", "x6"])
+def test_unet3d_full_width_matches_reference_fixture(arithmetic, dev):
+    """tests/golden/unet3d_dim64.npz (tools/gen_golden_r06.py): the REFERENCE's own Unet3D_with_Conv3D at the width of every BASELINE
+    config -- dim 64, mults (1, 2, 4): 8-channels-per-group GroupNorm, 64 / 128 / 256-wide attention -- on 2 x 8 x 16 x 16, with the
+    seeded synthetic weights (oracle.unet3d.synthetic_state_dict(seed): NumPy PCG64, rebuilt here, loaded strictly into the reference
+    by the generator).  Until r06 every dim-64 comparison was HIP <-> this repo's oracle only (VERDICT r05 weak #3)."""
+    from oracle import unet3d as O
+    from diffphycon_amd.model.video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    g = load_golden("unet3d_dim64")
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
+    m = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=6, arithmetic=arithmetic)
+    m.load_state_dict(O.synthetic_state_dict(cfg, seed=int(g["seed"])))
+    m = m.to(dev)
+    m.debug_taps(True)
+    y = m(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["t"]).to(dev)).cpu()
+    refs = [(k[4:], torch.from_numpy(g[k])) for k in g.files if k.startswith("tap:")]
+    _compare_taps(m, refs, dev, TAP_TOL, expect=6)
+    ref = torch.from_numpy(g["y"])
+    err = note_error("y", ((y - ref).abs().max() / ref.abs().max()).item())
+    assert err < OUT_TOL, err
+
+
 def test_unet3d_micro_batching_is_invisible(dev):
     g = load_golden("unet3d_joint")
     x, t = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["t"]).to(dev)

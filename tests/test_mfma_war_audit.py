@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # file -> (kernel-name fragments that must be found, minimal number of instantiations)
 FILES = {
     "conv3w.hip": ("conv3w_kernel", 4),
+    "conv3w4.hip": ("conv3w4_kernel", 4),
     "conv3f3c.hip": ("conv3f3c_kernel", 4),
     "igemm6.hip": ("igemm3_kernel", 4),
     "igemm_panel.hip": ("igemm3p_kernel", 24),

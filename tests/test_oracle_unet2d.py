@@ -42,3 +42,20 @@ def test_synthetic_state_dict_shapes():
     assert abs(n - 135.8e6) / 135.8e6 < 0.01                      # POPC joint model 135.8 M parameters
     cfg = U.Unet2DConfig(dim=64, dim_mults=(1, 2, 4))
     assert abs(sum(v.numel() for v in U.synthetic_state_dict(cfg).values()) - 9.9e6) / 9.9e6 < 0.02
+
+
+def test_oracle_at_the_popc_width_matches_the_reference_fixture():
+    """r06: tests/golden/unet2d_popc.npz = the REFERENCE's Unet2D at dim 64, mults (1, 2, 4, 8, 16), one GroupNorm group
+    (tools/gen_golden_r06.py) on the synthetic weights of the stored seed."""
+    g = load_golden("unet2d_popc")
+    mults = tuple(int(v) for v in g["dim_mults"])
+    cfg = U.Unet2DConfig(dim=64, dim_mults=mults, channels=2, out_dim=2, resnet_block_groups=1)
+    sd = U.synthetic_state_dict(cfg, seed=int(g["seed"]))
+    taps = {}
+    with torch.no_grad():
+        y = U.unet2d_forward(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), taps)
+    ref = torch.from_numpy(g["y"])
+    assert (y - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-6
+    for k in ("init_conv", "mid_block2", "final_res_block"):
+        r = torch.from_numpy(g["tap:" + k])
+        assert (taps[k] - r).abs().max() <= 1e-5 * r.abs().max() + 1e-6, k

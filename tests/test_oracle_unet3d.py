@@ -128,3 +128,24 @@ def test_edge_index_touches_every_tile_and_every_seam():
         assert set(range(F_)) <= set(f.tolist()) and set(range(H_)) <= set(h.tolist()) and set(range(W_)) <= set(w.tolist())
     assert len(G.edge_index((1, 256), 1)) == 0
     assert len(G.sample_index(41, 3, 8388608, (1, 64, 32, 64, 64), 1)) == G.NSAMP + len(G.edge_index((1, 64, 32, 64, 64), 1))
+
+
+def test_oracle_at_full_width_matches_the_reference_fixture():
+    """r06: tests/golden/unet3d_dim64.npz is the REFERENCE's forward at dim 64, mults (1, 2, 4) (tools/gen_golden_r06.py) on the
+    synthetic weights of the seed stored in the file -- the oracle is pinned to the reference at the width it is used as the
+    checker for (8 channels per GroupNorm group, 64 / 128 / 256-wide attention), not only at dim 8 / 16."""
+    g = load_golden("unet3d_dim64")
+    cfg = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=6)
+    sd = O.synthetic_state_dict(cfg, seed=int(g["seed"]))
+    taps = {}
+    with torch.no_grad():
+        y = O.unet3d_forward(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), taps=taps)
+    ref = torch.from_numpy(g["y"])
+    assert (y - ref).abs().max() <= 1e-5 * ref.abs().max(), (y - ref).abs().max()
+    n = 0
+    for k in g.files:
+        if k.startswith("tap:"):
+            r = torch.from_numpy(g[k])
+            assert (taps[k[4:]] - r).abs().max() <= 1e-5 * r.abs().max() + 1e-6, k
+            n += 1
+    assert n == 6

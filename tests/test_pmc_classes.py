@@ -27,6 +27,8 @@ CASES = {
     "void dpc::igemm3i_kernel<false, 9>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
     "void dpc::igemm3w_kernel<false, 64>(dpc::IgemmParams, unsigned char const*)": "igemm_bn64",
     "void dpc::igemm3w_kernel<true, 128>(dpc::IgemmParams, unsigned char const*)": "igemm_bn128",
+    "void dpc::conv3w4_kernel<true, 64>(dpc::Conv3hParams)": "conv3x6_bn64",
+    "void dpc::conv3w4_kernel<false, 128>(dpc::Conv3hParams)": "conv3x6_bn128",
     "void dpc::stem7x6_kernel<true, 8>(dpc::StemParams, unsigned char const*)": "stem_gather",
     "void dpc::stem7p_kernel<3>(dpc::StemParams, unsigned char const*)": "stem_gather",
     "void dpc::tattn3_kernel<64, true, 0>(dpc::TattnParams, unsigned char const*, unsigned char const*, float*)": "temporal_attention_fused",
