@@ -99,6 +99,42 @@ def step_roofline(modes, flop_per_step, sec_per_step, note):
             "peak_note": peak_note, "note": note}
 
 
+def mfma_issue(kernel_class, modes, achieved_tflops):
+    """What the matrix pipe actually ISSUES for the algorithmic rate `achieved`: products per fp32 product of the
+    class's arithmetic mode (f16x3: 3, x6: 6 on the 16-bit pipe; f32: 1 on the fp32 pipe) x the fraction of the direct form's products
+    the convolution algorithm keeps (3x3x3 convolutions: Winograd over frames F(4,3) 1/2, F(2,3) 2/3; everything else 1), against
+    the DENSE peak of that pipe -- `frac` prices algorithmic flop against peak / products, this one prices issued MFMA flop."""
+    fam = family_of(kernel_class)
+    mode = dict(kv.split("=") for kv in modes.split(",")).get(fam, "f32") if modes else "f32"
+    per, peak = {"f16x3": (3.0, PEAK_BF16_MFMA_TFLOPS), "x6": (6.0, PEAK_BF16_MFMA_TFLOPS)}.get(mode, (1.0, PEAK_FP32_MFMA_TFLOPS))
+    keep, alg = 1.0, None
+    if fam == "conv" and mode == "f16x3":
+        from diffphycon_amd import _lib
+        alg = _lib.lib().dpc_conv3d_algorithm().decode()
+        keep = {"winograd_f43_frames": 0.5, "winograd_f23_frames": 2.0 / 3.0}.get(alg, 1.0)
+    return {"mfma_issue_frac": achieved_tflops * per * keep / peak,
+            "mfma_issue_note": f"{per:g} MFMA products per fp32 product ({mode})" + (f" x {keep:.3f} of the direct form's products ({alg})" if alg else "")
+                               + f" / {peak:g} TFLOP/s dense"}
+
+
+def pmc_sq(kernel_class, workload):
+    """Matrix-pipe busy fraction and sustained shader clock of the class from the COMMITTED rocprofv3 --pmc SQ pass (profiles/pmc_sq.json,
+    tools/gpu_evidence.sh; stamped with the kernel sources like pmc_traffic.json) -- null when absent or stale.  Not measured by this run."""
+    out = {"mfma_busy_frac": None, "shader_clock_ghz": None}
+    if workload != "smoke":
+        return out
+    try:
+        row = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json"))).get(kernel_class, {})
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_summary import source_stamp
+        if row.get("kernel_source_sha16") is not None and row.get("kernel_source_sha16") == source_stamp(kernel_class):
+            out = {"mfma_busy_frac": row.get("mfma_busy_frac"), "shader_clock_ghz": row.get("shader_clock_ghz"),
+                   "pmc_sq_source": "committed rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (profiles/pmc_sq.json), not re-measured by this run"}
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def pmc_traffic(kernel_class, workload="smoke"):
     """HBM bytes per launch of a kernel class from the COMMITTED rocprofv3 --pmc passes (profiles/pmc_traffic.json for the S64 headline
     loop, profiles/pmc_traffic_<workload>.json for the burgers / train legs -- tools/pmc_legs.sh: FETCH_SIZE doubled per the guide's
@@ -173,8 +209,8 @@ def _timed_cpu_steps(step, budget_s, max_steps=5):
 
 def cpu_baseline(sd_cpu, budget_s):
     """the CPU oracle (the reference's algorithm restated in torch fp32) on the same unit, 1 warm-up +
-    up to 5 timed steps at B=1 and at B=min(4, cores) (r04: 8 cost 90 s for one warm-up + one timed step); `value` is the better of
-    the two rates."""
+    up to 5 timed steps at B=1 and at B=min(8, cores) -- the plan of record since r06 (--cpu-budget defaults to 420 s of host time
+    for all CPU legs: B = 8 costs ~45 s per step on the 16-thread host); `value` is the better of the two rates."""
     from oracle import unet3d as O
     from oracle import sampler_smoke as S
     cores = usable_cores()
@@ -183,7 +219,7 @@ def cpu_baseline(sd_cpu, budget_s):
     cw = O.Unet3DConfig(dim=64, dim_mults=(1, 2, 4), channels=2)
     sched = S.make_schedule(1000, "sigmoid")
     legs = []
-    for B, share in ((1, 0.4), (min(4, cores), 0.6)):
+    for B, share in ((1, 0.12), (min(8, cores), 0.88)):
         if legs and B == legs[0]["B"]:
             break
         g = torch.Generator().manual_seed(1)
@@ -345,6 +381,10 @@ def burgers_fd_leg(ctx, with_cpu, budget_s):
     return out
 
 
+def _worker_ready(i):
+    return i
+
+
 def _smoke_oracle_rollout(args):
     """One rollout on the NumPy oracle (a worker of smoke_evaluator's `cores`-process CPU leg)."""
     import numpy as np
@@ -449,6 +489,9 @@ def roofline_of(prof, prof_all, modes, sec_per_step, steps, warm_ms, unit_tflop_
     else:
         roof["traffic_source"] = (f"committed rocprofv3 --pmc passes of this leg at this batch (profiles/pmc_traffic_{pmc_workload}.json, "
                                   "tools/pmc_legs.sh: average over the class's launches), not re-measured by this run")
+    if roof["bound"] == "mfma":
+        roof.update(mfma_issue(name, modes, roof["achieved"]))
+        roof.update(pmc_sq(name, pmc_workload))
     roof["kernel"], roof["launches"] = name, d["launches"]
     roof["avg_launch_ms"] = d["total_ms"] / max(d["launches"], 1)
     if prof_all:
@@ -813,7 +856,11 @@ def run_smoke_evaluator(ctx, B=64, T=256, with_cpu=True):
         import multiprocessing as mp
         cores = usable_cores()
         one = _smoke_oracle_rollout((d0[0], c1[0], c2[0], T))
-        with mp.get_context("fork").Pool(cores) as pool:           # NumPy only in the workers; no GPU context is touched
+        # "spawn", not "fork" (ADVICE r05): the parent has initialised torch and the HIP runtime by now, and a forked child can inherit a
+        # locked allocator / runtime mutex.  Spawned workers re-import this module (NumPy oracle only, no GPU context); one untimed
+        # round-trip per worker first, so that their start-up is not in the timed region.
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_worker_ready, range(cores))
             t0 = time.perf_counter()
             per = pool.map(_smoke_oracle_rollout, [(d0[i % B], c1[i % B], c2[i % B], T) for i in range(cores)])
             wall = time.perf_counter() - t0
@@ -856,7 +903,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (S64 = 64)")
     ap.add_argument("--micro-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time for all cpu_baseline legs")
+    ap.add_argument("--cpu-budget", type=float, default=420.0,
+                    help="seconds of host time for all cpu_baseline legs (420: BASELINE.md section 3's step counts -- 5 timed steps at B = 1 and "
+                         "B = min(8, cores), 20 Burgers steps per mode -- fit; 60 gives the short r05 sample)")
     ap.add_argument("--no-extras", action="store_true", help="headline loop only: no exact-mode / burgers / evaluator legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the two real end-to-end passes (DDIM-100: ~30 s, DDPM-1000: ~270 s)")
     ap.add_argument("--stub", action="store_true",
@@ -1014,8 +1063,9 @@ def main():
                           "product; x6 = exact 3-way bf16 split, 6 MFMAs; f32 = native fp32 MFMA. value_exact re-times the same "
                           "loop in x6",
             "conv3d_algorithm": _lib.lib().dpc_conv3d_algorithm().decode() + " (reported by the library: dpc_conv3d_algorithm; "
-                                "winograd_f23_frames = F(2,3) minimal filtering along the frame axis, 36 instead of 54 tap products "
-                                "per output-frame pair; roofline.achieved counts algorithmic direct-form FLOP either way)",
+                                "winograd_f43_frames = F(4,3) minimal filtering along the frame axis, 54 tap products per four output "
+                                "frames where the direct form has 108 and F(2,3) 72; roofline.achieved counts algorithmic direct-form "
+                                "FLOP either way, roofline.mfma_issue_frac what is issued)",
             "config": {"workload": f"{cfg_name}, 1000-step guided DDPM, batch={B} per GPU; one step = joint+prior Unet3D(dim 64, "
                                    "mults 1-2-4) forward + fused guidance/posterior update; trajectories/s = batch/(1000*s_per_step)",
                        "global_batch": world * B, "micro_batch": mbatch, "parallelism": f"batch-shard x{world}"},
@@ -1072,6 +1122,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd_cpu, args.cpu_budget * 0.8)
         else:
             out["cpu_baseline"] = None
+        # short scalars first (a truncated line still carries both arithmetic modes' values), then the two contract objects, then the legs
+        front = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min_rank", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "value_exact", "ms_per_step_exact", "dtype_exact", "data", "config", "roofline", "cpu_baseline"]
+        out = {**{k: out[k] for k in front if k in out}, **{k: v for k, v in out.items() if k not in front}}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

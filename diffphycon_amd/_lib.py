@@ -125,7 +125,7 @@ _SIGNATURES = {
     "dpc_conv_free": (None, [_P]),
     "dpc_conv_run": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P] + [_I] * 5 + [_P, _P, _I, _I, _I, C.c_float, _I, _P]),
     "dpc_gn_workspace_bytes": (_Z, [_I, _I]),
-    "dpc_conv_gn_fusable": (C.c_int, [_P, _I, _I]),
+    "dpc_conv_gn_fusable": (C.c_int, [_P, _I, _I, _I, _I]),
     "dpc_conv_gn_entries": (_L, [_I, _I]),
     "dpc_conv_run_gn": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "dpc_gn_finalize_fused": (C.c_int, [_P, _I, _L, _I, _I, _L, _P, _P, _P, _P, _P, _P]),
@@ -235,6 +235,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m diffphycon_amd.build` "
                 "(diffphycon_amd has no non-HIP fallback)")
         L = C.CDLL(LIB_PATH)
+        # an older build (or a DPC_LIB override) that lacks an entry point of include/dpc.h is refused with the rebuild message, not with
+        # a bare AttributeError from the loop below; the build stamp is the first thing asked for
+        absent = [name for name in _SIGNATURES if not hasattr(L, name)]
+        if absent:
+            raise RuntimeError(f"{LIB_PATH} does not export {', '.join(absent[:4])}{' ...' if len(absent) > 4 else ''} "
+                               f"({len(absent)} of {len(_SIGNATURES)} symbols of include/dpc.h): it was built from another version of the "
+                               "sources; rebuild with `python -m diffphycon_amd.build --force`")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -47,6 +47,10 @@ def scan_packed_fp32(path):
     import re
     import shutil
     import tempfile
+    tool = os.path.join(LLVM_BIN, "llvm-objdump")
+    if not os.path.exists(tool):
+        raise RuntimeError(f"{tool} not found: the build disassembles the linked device code to stamp the library (packed fp32 "
+                           "instruction count); point DPC_LLVM_BIN at the directory that holds llvm-objdump")
     d = tempfile.mkdtemp(prefix="dpc_scan_")
     try:
         tmp = os.path.join(d, os.path.basename(path))

@@ -27,11 +27,16 @@
 //     channels) AND one 32-channel half (w & 1) of component 4 + (w >> 1): 6 accumulator tiles (96 registers), 18 MFMAs per tap, 162
 //     per chunk (conv3w: 216).  Price: each weight fragment now serves 64 points instead of 128 -- 2 x the L2 -> L1 weight bytes per MFMA
 //     (measured on conv3w with doubled weight requests: + 10 %, profiles/r06_a_wtraffic_ab.log).  Transformed weights
-//     [6][9 taps][chunk][n][2 planes][16] fp16 (launch_pack_weights_w4), two running pointers, 3-deep register ring.
+//     [6][9 taps][chunk][n / 32][2 planes][2 k-halves][32 n][8] fp16 (launch_pack_weights_w4: fragment order, a load is 1 KB
+//     contiguous), two running pointers, 3-deep register ring.
 //     Fragment re-loads keep conv3w's rule (a set is re-loaded >= 4 MFMAs after its last reader was issued and 8 MFMAs before its
 //     next reader: DESIGN.md 6.2, third hazard): three sets -- component A rows 0-3, rows 4-7, component B -- rotate through the
 //     three 6-MFMA groups of a tap.  (Measured and dropped, profiles/r06_e_term_major_ab.log: all four sets double-buffered and the
-//     18 MFMAs of a tap in term-major order over the six tiles -- an accumulator revisited after 6 instead of 2 MFMAs -- is 11 % SLOWER.)
+//     18 MFMAs of a tap in term-major order over the six tiles -- an accumulator revisited after 6 instead of 2 MFMAs -- is 11 % SLOWER;
+//     profiles/r06_j_spread_ab.log: the six weight requests of a tap spread over the tap, one behind every second MFMA, instead of six in
+//     a row: no difference (+0.7 %).)  What bounds the tap phase is the CU's vector-memory path: 216 KB of weight fragments + 38 KB of halo
+//     per chunk through 64 B / clk = 3970 of the chunk's 5184 MFMA-issue cycles (profiles/r06_i_stamps_dbg.log: without the weight
+//     stream the tap phase is 0.64 of its length; r06_h_stamps.log: taps 7.7 k cycles per chunk, the loader waves idle 45 % of theirs).
 //   * Epilogue: ONE exchange per tile (conv3w: one per frame pair).  The four MFMA waves park all six components in LDS (96 KB: halo
 //     buffer 1, which every tile leaves last, and the otherwise unused tail), the loader waves read them between two barriers --
 //     wave l takes plane rows 2l, 2l+1 of all four output frames and both channel halves: 6 reads per 4 output values -- combine,
@@ -40,7 +45,8 @@
 // Rounding: U in fp32 from the fp32 weights before the split, V in fp32 after the fused activation; the same 22-bit f16x3 products
 // with fp32 accumulation.  tests/test_gpu_ops.py bounds the per-convolution error (see there for the measured values).
 // Perf attribution (DPC_ENABLE_CONV_DBG builds, env DPC_CONV_DBG; results INVALID): 2 the loader skips its global loads, 32 the
-// loader does nothing but the barriers, 8 no epilogue, 4 every MFMA wave streams component 0's weights for both of its streams.
+// loader does nothing but the barriers, 8 no epilogue, 4 every MFMA wave streams component 0's weights for both of its streams,
+// 16 weight fragments are loaded once (three taps' worth, then re-used), 64 activation fragments are read from LDS during the first chunk only.
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:189-204).
 #include "common.h"
 #include "f3c.h"
@@ -96,6 +102,26 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
         b = t / ntf;
     };
     if (nsteps == 0) return;
+#ifdef DPC_CONV_STAMPS
+    // attribution builds (tools/conv_stamps_w4.py; results INVALID: the totals overwrite the head of the output): per wave, shader cycles
+    // spent in each phase, summed over the launch.  MFMA waves: 0 taps, 1 accumulator drain, 2 chunk barrier, 3 epilogue writes,
+    // 4 epilogue barriers.  Loader waves: 0 request, 1 wait for the halo, 2 activation / transform / split / LDS writes, 3 deferred stores,
+    // 4 chunk barrier, 5 epilogue.  Slot 7: lifetime.
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tbirth = tlast;
+    auto lap = [&](int k) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[k] += t - tlast; tlast = t; };
+    auto lap_out = [&]() {
+        tacc[7] = __builtin_amdgcn_s_memtime() - tbirth;
+        if (lane == 0) {
+            float* rec = p.out + ((long long)blockIdx.x * 8 + wave) * 8;
+            for (int i = 0; i < 8; ++i) rec[i] = (float)tacc[i];
+        }
+    };
+#else
+    auto lap = [&](int) {};
+    auto lap_out = [&]() {};
+#endif
 
     if (wave >= 4) {
         // ======================================================================================= loader waves
@@ -404,10 +430,15 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
         // exists once in the code and the buffer a tile leaves behind is always buffer 1.
         auto body = [&](long long s, f32x4 (&X)[2][HFI], StepState& sx, f32x4 (&Y)[2][HFI], StepState& sy, int boff, int slot) {
             if (s + 2 < nsteps) { advance(); request(Y, sy); }
+            lap(0);
             if (s + 1 < nsteps) landed(X, sx.cf, s + 2 < nsteps);
+            lap(1);
             if (s + 1 < nsteps) finish(sx.kc, sx.fok, sx.in0, sx.in1, X, sx.cf, boff);   // the MFMA waves left that buffer at the previous barrier
+            lap(2);
             drain(slot);
+            lap(3);
             lds_done_barrier();
+            lap(4);
         };
         long long s = 0;
         for (int j = 0; j < ntiles; ++j) {
@@ -417,9 +448,11 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
                 s += 2;
             }
             if (!(CONV_DBG_BUILD && (p.dbg & 8))) epilogue(j, halo + XCH);
+            lap(5);
         }
         for (int slot = 0; slot < 8; ++slot) drain(slot);       // the last tile
         __builtin_amdgcn_s_waitcnt(0);
+        lap_out();
         return;
     }
 
@@ -444,7 +477,10 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
     const bool dbg_w0 = CONV_DBG_BUILD && (p.dbg & 4);   // attribution: every wave streams component 0's weights, stream B = stream A (L1 hits)
     const unsigned char* wroot = reinterpret_cast<const unsigned char*>(p.wpw) + (dbg_w0 ? 0ll : (long long)compA * NTAPS * wtap);
     const long long wdelta = dbg_w0 ? 0ll : (long long)(compB - compA) * NTAPS * wtap + (long long)ntB * 32 * WROW;
-    const int wlo = l31 * WROW + hh * 16;
+    // FRAGMENT-order pack (as the implicit GEMM's since r03): per (component, tap, chunk) and 32-channel column block
+    // [plane 2][k-half 2][n 32][8 fp16] = 2 KB, so the 16 bytes lane (n, k-half) feeds to one MFMA are contiguous across the wave -- a
+    // fragment load is 1 KB = 8 cache lines (the [n][plane][16 k] rows of conv3w: 32 half-used 64-byte rows per instruction)
+    const int wlo = hh * 512 + l31 * 16;
     const unsigned char* wlane = wroot;
     const unsigned char* wnext = wroot;
     int wtap_i = 0, wkc_i = 0, wtile = 0;
@@ -453,7 +489,9 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
         decode(j < ntiles ? j : ntiles - 1, n0, w0, h0, f0, b);
         return n0;
     };
+    bool dbg_w_once = false;                              // attribution bit 16: weight fragments are loaded for the first two taps only
     auto ldw = [&](f16x8 (&da)[2][2], f16x8 (&db)[2]) {
+        if (CONV_DBG_BUILD && (p.dbg & 16) && dbg_w_once) return;
         const unsigned char* src = wnext + wlo;
         if (++wtap_i == NTAPS) {
             wtap_i = 0;
@@ -465,18 +503,24 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) da[nt][pl] = *reinterpret_cast<const f16x8*>(src + nt * 32 * WROW + pl * 32);
+            for (int pl = 0; pl < 2; ++pl) da[nt][pl] = *reinterpret_cast<const f16x8*>(src + nt * 32 * WROW + pl * 1024);
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) db[pl] = *reinterpret_cast<const f16x8*>(src + wdelta + pl * 32);
+        for (int pl = 0; pl < 2; ++pl) db[pl] = *reinterpret_cast<const f16x8*>(src + wdelta + pl * 1024);
     };
     wlane = wroot + (long long)tile_n0(0) * WROW;
     wnext = wlane;
     ldw(wA[0], wB[0]);
     ldw(wA[1], wB[1]);
+    if (CONV_DBG_BUILD && (p.dbg & 16)) {
+        ldw(wA[2], wB[2]);
+        dbg_w_once = true;
+    }
 
     int boff = 0;
     // fragments of slab q (plane rows 4 q .. 4 q + 3) of a component's transformed frame for tap (dh, dw): both planes
+    bool dbg_a_once = false;                              // attribution bit 64: activation fragments are read from LDS once per launch
     auto lda = [&](f16x8 (&dst)[2], int addr, int q) {
+        if (CONV_DBG_BUILD && (p.dbg & 64) && dbg_a_once) return;
         dst[0] = *reinterpret_cast<const f16x8*>(halo + addr + q * 2560);
         dst[1] = *reinterpret_cast<const f16x8*>(halo + (addr ^ 32) + q * 2560);
     };
@@ -554,13 +598,17 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
             };
 #pragma unroll
             for (int tap = 0; tap < NTAPS; ++tap) tap_body(tap);
+            lap(0);
+            if (CONV_DBG_BUILD && (p.dbg & 64)) dbg_a_once = true;
             // MFMA B-operand guard (third hazard): the next chunk's first fragment loads may be given the registers of the
             // fragments the last MFMAs read (hipcc re-uses them: tools/mfma_war_audit.py) -- the wave waits for the last MFMA of both
             // component-B chains (the youngest six MFMAs of the chunk) before it enters the barrier
             mfma_drain(accB[0]);
             mfma_drain(accB[1]);
             __builtin_amdgcn_sched_barrier(0);
+            lap(1);
             wg_barrier();                                  // next chunk's buffer is complete; this one may be overwritten
+            lap(2);
             boff = HB1 - boff;
         }
 
@@ -586,9 +634,12 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
                 *reinterpret_cast<f32x4*>(xw + compB * 16384 + ntB * 8192 + q * 4096 + ((tsw ^ (2 * g)) << 4)) = v;
             }
         }
+        lap(3);
         lds_done_barrier();                                // E1: the six components are in LDS
         wg_barrier();                                      // E2: the loader waves have read them
+        lap(4);
     }
+    lap_out();
 }
 
 bool conv3w_f43_enabled() {
@@ -630,7 +681,7 @@ int launch_conv3w4(const Conv3hParams& p, hipStream_t s) {
     return DPC_OK;
 }
 
-// ---- weight transform + pre-split: reference [N][K][3][3][3] fp32 -> [6 k][9 taps][kchunks][Npad][2 planes][16] fp16 (x 2^12)
+// ---- weight transform + pre-split: reference [N][K][3][3][3] fp32 -> [6 k][9 taps][kchunks][Npad / 32][2 planes][2 k-halves][32 n][8] fp16 (x 2^12)
 __global__ void pack_weights_w4_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int N, int Npad, int K,
                                        int kchunks, int* __restrict__ ovf) {
     const long long total = (long long)54 * kchunks * Npad * 16;
@@ -663,9 +714,10 @@ __global__ void pack_weights_w4_kernel(const float* __restrict__ w, unsigned sho
         const unsigned p1 = f3c::cvt_pk_f16(v, 0.f) & 0xffffu;
         const float h1 = (float)__builtin_bit_cast(f3c::f16x2, p1).x;
         const unsigned p2 = f3c::cvt_pk_f16(v - h1, 0.f) & 0xffffu;
-        unsigned short* dst = wp + (((long long)kt * kchunks + kc) * Npad + n) * 32 + kk;
+        // fragment order: 32-column block n >> 5, then [plane][k-half][n & 31][8]
+        unsigned short* dst = wp + (((long long)kt * kchunks + kc) * Npad + (n & ~31)) * 32 + ((kk >> 3) * 32 + (n & 31)) * 8 + (kk & 7);
         dst[0] = (unsigned short)p1;
-        dst[16] = (unsigned short)p2;
+        dst[512] = (unsigned short)p2;
     }
 }
 

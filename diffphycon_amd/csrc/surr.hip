@@ -655,10 +655,13 @@ int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1,
 }
 
 // ---- GroupNorm fused around a ResnetBlock's two 3x3 convolutions (r05; see include/dpc.h)
-int dpc_conv_gn_fusable(dpc_conv_t h, int H, int W) {
-    if (!h) return 0;
+int dpc_conv_gn_fusable(dpc_conv_t h, int H, int W, int C0, int C1) {
+    // exactly run_conv's condition for the halo-tile path of a stride-1 3x3 convolution (unet3d.hip: flat_halo) -- a split input whose parts
+    // are not multiples of 4 channels, or DPC_CONV2D_HALO=0, must send the caller to its unfused GroupNorm passes, not into a
+    // DPC_REQUIRE of dpc_conv_run_gn
+    if (!h || C0 + C1 != h->pc.K) return 0;
     ModeScope scope(h->modes);
-    return (h->pc.flat3 && conv2d_gn_fusable(h->pc.N, h->pc.Npad, H, W)) ? 1 : 0;
+    return (h->pc.flat3 && C0 % 4 == 0 && C1 % 4 == 0 && conv2d_gn_fusable(h->pc.N, h->pc.Npad, H, W)) ? 1 : 0;
 }
 int64_t dpc_conv_gn_entries(int H, int W) { return conv3f3c_flat_gn_entries(H, W); }
 int dpc_conv_run_gn(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, float* out, int images, int H, int W,
@@ -666,7 +669,7 @@ int dpc_conv_run_gn(dpc_conv_t h, const float* a0, const float* a1, int C0, int 
     DPC_REQUIRE(h && a0 && out && images >= 1, "conv_run_gn: null argument");
     DPC_REQUIRE(gn_part || in_coef, "conv_run_gn: neither statistics output nor input coefficients (use dpc_conv_run)");
     DPC_REQUIRE(!in_coef || (!a1 && C1 == 0), "conv_run_gn: a fused input normalisation needs a single source");
-    DPC_REQUIRE(dpc_conv_gn_fusable(h, H, W), "conv_run_gn: this convolution / image size does not take the halo kernel (dpc_conv_gn_fusable)");
+    DPC_REQUIRE(dpc_conv_gn_fusable(h, H, W, C0, a1 ? C1 : 0), "conv_run_gn: this convolution / image size does not take the halo kernel (dpc_conv_gn_fusable)");
     ModeScope scope(h->modes);
     return run_conv(h->pc, a0, a1, C0, C1, bias, nullptr, out, images, 1, H, W, H, W, nullptr, nullptr, 0, 0, 0, (hipStream_t)stream, gn_part,
                     in_coef, nullptr, nullptr, 0.f, 0);

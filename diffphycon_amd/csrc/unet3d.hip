@@ -155,7 +155,8 @@ int pack_conv3d(PackedConv& pc, const float* w, int N, int K, int kd, int kh, in
 }
 
 bool conv2d_gn_fusable(int N, int Npad, int H, int W) {
-    return conv_mode_default() == 2 && conv3f3c_flat_gn_ok(N, Npad, H, W);
+    static const int flat_ok = debug_switch("DPC_CONV2D_HALO", 1);       // (the same switch run_conv reads: the two must not diverge)
+    return flat_ok && conv_mode_default() == 2 && conv3f3c_flat_gn_ok(N, Npad, H, W);
 }
 
 bool conv_can_fuse_gn_residual(const PackedConv& pc, long long rows_per_sample) {

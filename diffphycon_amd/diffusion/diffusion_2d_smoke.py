@@ -61,6 +61,11 @@ def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
     return torch.clip(betas, 0, 0.999)
 
 
+def _env_retry_exact():
+    import os
+    return os.environ.get("DPC_RANGE_RETRY_X6", "0") == "1"
+
+
 def _begin_noise_epoch(gd):
     """First Philox draw index of a sample() call: 4096 draws per epoch (a chain uses <= 1004).  The epoch is the call
     count unless the caller pinned `noise_epoch` (inference scripts pin 0 and key the noise by the global trajectory id,
@@ -310,15 +315,35 @@ class GaussianDiffusion(nn.Module):
         image_size, channels, frames = self.image_size, self.channels, self.frames
         sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
         assert batch_size == init.shape[0]
-        self._draw = _begin_noise_epoch(self)
+        self._draw = draw0 = _begin_noise_epoch(self)
         sample_size = (batch_size, frames, channels, image_size, image_size)
         out = sample_fn(sample_size, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low,
                         device=device)
         # the always-on f16x3 range sentinel (include/dpc.h: dpc_unet3d_range_status): ONE host sync per sample() call -- a
-        # checkpoint whose activations leave |x| <= 4094 fails here, loudly, instead of returning clamped results
-        for m in (self.model_joint, self.model_thetas):
-            if hasattr(m, "check_range"):
+        # checkpoint whose activations leave |x| <= 4094 fails here, loudly, instead of returning clamped results ...
+        try:
+            for m in (self.model_joint, self.model_thetas):
+                if hasattr(m, "check_range"):
+                    m.check_range()
+        except RuntimeError as e:
+            # ... or, opt-in (`gd.retry_exact = True`, env DPC_RANGE_RETRY_X6=1): slow and right instead of an
+            # exception.  Both denoisers are re-created in the exact mode (x6: bf16x6 products, no range limit below fp32's own), the
+            # SAME noise epoch is replayed -- the chain restarts from the same draws -- and the models STAY exact afterwards (a
+            # checkpoint that left the f16x3 window once will do so again).
+            if not getattr(self, "retry_exact", _env_retry_exact()) or "left the range" not in str(e):
+                raise
+            import warnings
+            warnings.warn("f16x3 activation range left during sample(): re-running this call in the exact x6 arithmetic "
+                          f"(about 2.6 x slower); the denoisers stay in x6 from here on.  Library message: {e}")
+            for m in (self.model_joint, self.model_thetas):
+                m.set_arithmetic("x6")
+                m.check_range()                      # (clears a flag the other model may still hold; handle-less: no-op)
+            self._draw = draw0
+            out = sample_fn(sample_size, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low,
+                            device=device)
+            for m in (self.model_joint, self.model_thetas):
                 m.check_range()
+            self.exact_retries = getattr(self, "exact_retries", 0) + 1
         return out
 
 

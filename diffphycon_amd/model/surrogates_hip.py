@@ -114,8 +114,9 @@ class _Conv:
         return out
 
 
-def _conv_gn_fusable(conv, H, W):
-    return bool(_lib.lib().dpc_conv_gn_fusable(conv.h, H, W))
+def _conv_gn_fusable(conv, H, W, C0, C1=0):
+    """the library's own predicate for the halo-tile path (include/dpc.h): False sends the caller to the standalone GroupNorm passes"""
+    return bool(_lib.lib().dpc_conv_gn_fusable(conv.h, H, W, C0, C1))
 
 
 def _conv_run_gn(conv, a0, images, H, W, a1=None, bias=None, part=None, in_coef=None):
@@ -250,7 +251,8 @@ class _Res:
     def forward(self, x0, x1, temb, n, H, W):
         ctx, R, Cc = self.ctx, H * W, self.Cout
         ss = ctx.linear(temb, self.mlp[0], self.mlp[1], in_act=1) if (self.mlp is not None and temb is not None) else None
-        if _FUSED_GN and _conv_gn_fusable(self.c1, H, W) and _conv_gn_fusable(self.c2, H, W):
+        if (_FUSED_GN and _conv_gn_fusable(self.c1, H, W, x0.shape[-1], x1.shape[-1] if x1 is not None else 0)
+                and _conv_gn_fusable(self.c2, H, W, Cc)):
             # r05: statistics from the conv epilogues, block1's GroupNorm + (scale, shift) + SiLU inside conv2's halo load: the activated
             # tensor a1 never exists (the backward recomputes it from raw1 / st1 as before) -- 3 passes per block instead of 7
             L = _lib.lib()

@@ -295,6 +295,18 @@ class Unet3D_with_Conv3D(nn.Module):
         self._ensure_handle()
         _lib.check(_lib.lib().dpc_unet3d_set_range_check(self._handle, int(enable)))
 
+    def set_arithmetic(self, arithmetic):
+        """Re-create the library handle in another arithmetic mode (None = the process-wide default, 'f16x3' | 'x6' | 'f32'): the mode
+        is captured when a handle is created (include/dpc.h), so the old handle is destroyed and the weights are re-loaded -- and
+        re-packed for the new mode -- at the next forward.  Used by the samplers' opt-in exact retry (GaussianDiffusion.retry_exact)."""
+        if arithmetic == self.arithmetic:
+            return
+        if self._handle is not None:
+            _lib.lib().dpc_unet3d_destroy(self._handle)
+            self._handle = None
+        self.arithmetic = arithmetic
+        self._dirty, self._frames, self._device = True, None, None
+
     def check_range(self, reset=True):
         """Raise if any forward since the last check produced a residual-stream activation outside the f16x3 range (|x| > 4094
         or non-finite): the always-on sentinel of include/dpc.h dpc_unet3d_range_status.  One host sync; the samplers call it

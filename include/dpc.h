@@ -46,7 +46,9 @@ const char* dpc_build_info(void);
  * of the device (default), else at most `cus` (rounded down to a multiple of 8, one share per XCD) workgroups per launch.  The smoke
  * entry script sets 192 while a batch's PDE rollouts (64 CUs for ~2 s: csrc/smoke_rollout.hip) run on a side stream under the next
  * batch's sampling (inference/inference_2d_smoke.py InferencePipeline.run; reference schedule: inference_2d_smoke.py:259-271 runs them
- * one after the other).  Results do not depend on the value (the tile -> workgroup map changes, no arithmetic does). */
+ * one after the other).  Results do not depend on the value (the tile -> workgroup map changes, no arithmetic does).
+ * PROCESS-WIDE: one global read at launch-enqueue time by every handle, thread, stream and device of the process -- meant for the
+ * one-rank-per-process deployment (one GPU, one pipeline); a process that drives several pipelines must serialise its use. */
 int dpc_set_cu_budget(int cus);
 const char* dpc_last_error(void);
 
@@ -245,13 +247,13 @@ int dpc_conv_run(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1,
                  int par_b, float act_scale, int a0_stride, dpc_stream_t stream);
 /* GroupNorm fused around the two 3x3 convolutions of a ResnetBlock (r05; diffusion_2d_jellyfish.py:122-148 Block / ResnetBlock, the same
  * fusion the 2-D denoiser uses internally): where dpc_conv_gn_fusable says the convolution runs on the halo-tile kernel (f16x3 mode, 3x3
- * stride 1, N % 64 == 0, H % 8 == 0, W % 8 == 0 -- shape only, never the batch), dpc_conv_run_gn
+ * stride 1, N % 64 == 0, H % 8 == 0, W % 8 == 0, C0 % 4 == 0, C1 % 4 == 0 -- shape only, never the batch; 0 = use the standalone GroupNorm passes), dpc_conv_run_gn
  *   - with gn_part != NULL also emits per-image partial sums of its OUTPUT, [images][dpc_conv_gn_entries(H, W)][N][2] floats, from which
  *     dpc_gn_finalize_fused forms stats [images][groups][2] = (mean, rstd) -- no statistics pass over the tensor -- and, with coef != NULL
  *     ([images * C * 7] floats), the per-channel coefficients of GN -> x (scale + 1) + shift (scale_shift [images][2C] or NULL);
  *   - with in_coef != NULL (that table) applies GroupNorm + (scale, shift) + SiLU to its INPUT on the fly: the activated tensor of
  *     block1 never exists in HBM.  Zero padding applies to the activated tensor, as in the reference. */
-int dpc_conv_gn_fusable(dpc_conv_t h, int H, int W);
+int dpc_conv_gn_fusable(dpc_conv_t h, int H, int W, int C0, int C1);    /* C0 + C1 = the input channels of the two (virtually concatenated) sources */
 int64_t dpc_conv_gn_entries(int H, int W);
 int dpc_conv_run_gn(dpc_conv_t h, const float* a0, const float* a1, int C0, int C1, const float* bias, float* out, int images, int H, int W,
                     float* gn_part, const float* in_coef, dpc_stream_t stream);

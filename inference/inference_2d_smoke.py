@@ -71,13 +71,18 @@ class InferencePipeline(object):
         self.sim = init_sim_128()
         os.makedirs(self.results_path, exist_ok=True)
 
-    def run_model(self, state):
-        """state: not rescaled [B, 256, 6, 64, 64] -> sampled + rescaled [B, 32, 6, 64, 64]   (:179-197)"""
+    def prepare_inputs(self, state):
+        """The sampler's conditioning of a batch (:179-186) as device tensors: torch element-wise kernels on the sampling stream.  The
+        overlapped schedule calls this for batch i + 1 BEFORE batch i's rollouts are enqueued on the side stream, so that none of
+        these kernels runs beside a rollout (torch's kernels contain packed fp32 instructions)."""
         state = state[:, ::8].to(self.args_general.device)          # (slice on the host: 0.2 GB over PCIe instead of 1.6 GB; same values)
-        output = self.model[0].sample(
-            batch_size=state.shape[0], design_fn=self.args["design_fn"], design_guidance=self.args["design_guidance"],
-            low=None, init=state[:, 0, 0] / self.RESCALER[:, 0, 0], init_u=state[:, 0, 0],
-            control=state[:, :, 3:5] / self.RESCALER[:, :, 3:5])
+        return dict(batch_size=state.shape[0], init=(state[:, 0, 0] / self.RESCALER[:, 0, 0]).contiguous(), init_u=state[:, 0, 0].contiguous(),
+                    control=(state[:, :, 3:5] / self.RESCALER[:, :, 3:5]).contiguous())
+
+    def run_model(self, state, prepared=None):
+        """state: not rescaled [B, 256, 6, 64, 64] -> sampled + rescaled [B, 32, 6, 64, 64]   (:179-197)"""
+        kw = prepared if prepared is not None else self.prepare_inputs(state)
+        output = self.model[0].sample(design_fn=self.args["design_fn"], design_guidance=self.args["design_guidance"], low=None, **kw)
         if getattr(self, "_side_stream", None) is not None:
             # overlapped schedule: the torch element-wise kernels below must not run beside the previous batch's rollouts (torch's kernels
             # contain packed fp32 instructions: DESIGN.md 6.2).  Normally the rollouts ended ~24 s ago; a very short chain waits here.
@@ -124,11 +129,12 @@ class InferencePipeline(object):
     def _evaluate_enqueue(self, pred, data):
         return self._metric_rows(*self._rollouts_enqueue(pred, data))
 
-    def _evaluate_report(self, rows, start):
-        """The host side of multi_evaluate: ONE read of the batch means, the reference's print lines."""
+    def _evaluate_report(self, rows, start, elapsed=None):
+        """The host side of multi_evaluate: ONE read of the batch means, the reference's print lines.  `elapsed`: the evaluator's own
+        time when it ran overlapped (device events around the rollouts + the metric rows), else wall time since `start` (:317, :425)."""
         self.last_rows = rows               # run() gathers them ONCE after its loop (ranks may own different batch counts)
         m = rows.mean(0).cpu().numpy()
-        print(f"Time cost: {time.time() - start}")
+        print(f"Time cost: {time.time() - start if elapsed is None else elapsed}")
         print("J_total=J_target+w*J_energy=", m[1], "+", self.args_general.w_energy, "*", m[2], "=", m[0])
         print("mse=", m[3], "normalized_l2=", m[4])
         return tuple(np.array([v]) for v in m)
@@ -144,7 +150,8 @@ class InferencePipeline(object):
         for ~2 s: one persistent workgroup per rollout -- is enqueued on a SIDE stream and runs under batch i + 1's sampling (r05;
         `--overlap_evaluator False` restores the serial schedule).  Same kernels, same inputs: the metric rows are bit-identical to
         the serial run (tests/test_gpu_inference_scripts.py).  While a rollout is in flight the persistent sampling kernels are
-        told to size their grids for the CUs that are left (include/dpc.h: dpc_set_cu_budget)."""
+        told to size their grids for the CUs that are left (include/dpc.h: dpc_set_cu_budget -- a PROCESS-WIDE library setting: it applies
+        to every handle, thread and device of the process, which is one rank = one GPU = one pipeline here; reset in `finally`)."""
         J = {k: [] for k in ("J_total", "J_target", "J_energy", "mse", "n_l2")}
         rows = []
         overlap = bool(getattr(self.args_general, "overlap_evaluator", True)) and len(dataloader) > 1
@@ -175,22 +182,33 @@ class InferencePipeline(object):
             side.synchronize()               # the rollouts are done; the sampling stream is idle too (sample() ends with a host read)
             L.dpc_set_cu_budget(0)
             self.model[0].step_callback = None
-            out = self._evaluate_report(self._metric_rows(*pend[0]), pend[1])
+            t_rows = time.time()
+            rows_i = self._metric_rows(*pend[0])
+            torch.cuda.current_stream().synchronize()
+            # "Time cost" as the reference means it -- the evaluator's time -- not the ~25 s that passed since it was enqueued (the next
+            # batch was sampled meanwhile): rollouts by device events on the side stream + the metric-row kernels and their host read
+            out = self._evaluate_report(rows_i, pend[1], elapsed=pend[4].elapsed_time(pend[3]) * 1e-3 + (time.time() - t_rows))
             rows.append(self.last_rows)
             for key, v in zip(J, out):
                 J[key].append(v)
 
         try:
-            for i, (state, sim_id) in enumerate(dataloader):
+            batches = iter(dataloader)
+            nxt = next(batches, None)
+            prepared = self.prepare_inputs(nxt[0]) if (overlap and nxt is not None) else None
+            i = -1
+            while nxt is not None:
+                (state, sim_id), i = nxt, i + 1
                 print(f"Batch No.{i}")
                 note(f"batch {i}: loader returned")
                 ids = [int(v) for v in sim_id]
                 assert ids == list(range(ids[0], ids[0] + len(ids))), "batches must hold consecutive simulation ids"
                 # noise keyed by the global simulation id (Philox): independent of batch size and of the sharding over ranks
                 self.model[0].traj_offset, self.model[0].noise_epoch = ids[0], 0
-                pred = self.run_model(state)
+                pred = self.run_model(state, prepared)
                 note(f"batch {i}: run_model returned")
                 print("pred shape: ", pred.shape)
+                nxt = next(batches, None)
                 if not overlap:
                     out = self.multi_evaluate(pred, state, plot=False, method=self.args_general.inference_method)
                     rows.append(self.last_rows)
@@ -199,16 +217,20 @@ class InferencePipeline(object):
                     continue
                 if pending is not None:
                     finish(pending)              # batch i - 1's rollouts ran beside this batch's sampling
+                # the NEXT batch's conditioning tensors are formed now, while nothing else is resident (see prepare_inputs)
+                prepared = self.prepare_inputs(nxt[0]) if nxt is not None else None
                 done = torch.cuda.Event()
-                done.record()                    # pred is complete on the sampling stream
+                done.record()                    # pred (and the prepared inputs) are complete on the sampling stream
                 start = time.time()
                 with torch.cuda.stream(side):
                     side.wait_event(done)
+                    began = torch.cuda.Event(enable_timing=True)
+                    began.record()
                     r = self._rollouts_enqueue(pred, state)
-                    rolled = torch.cuda.Event()
+                    rolled = torch.cuda.Event(enable_timing=True)
                     rolled.record()              # on the side stream: the rollouts are complete (the metric rows follow in finish())
                 note(f"batch {i}: evaluator enqueued on the side stream")
-                pending = (r, start, pred, rolled)
+                pending = (r, start, pred, rolled, began)
                 if budget > 0:
                     L.dpc_set_cu_budget(budget)  # the next batch's persistent kernels leave the rollouts' CUs alone ...
                     self.model[0].step_callback = release_budget          # ... until the rollouts are done

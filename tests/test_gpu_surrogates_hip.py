@@ -118,7 +118,8 @@ def test_conv_with_per_image_groupnorm_hooks(dev, n, H, W, Ci, Co, groups):
     act = F.silu(gn * (ss[:, :Co, None, None] + 1) + ss[:, Co:, None, None])
     raw2_ref = F.conv2d(act, w2, b2, padding=1)
     c1, c2 = SH._Conv(w1.float()), SH._Conv(w2.float())
-    assert SH._conv_gn_fusable(c1, H, W) and SH._conv_gn_fusable(c2, H, W)
+    assert SH._conv_gn_fusable(c1, H, W, x.shape[1]) and SH._conv_gn_fusable(c2, H, W, Co)
+    assert not SH._conv_gn_fusable(c1, H, W, x.shape[1] - 2, 2)          # a split whose parts are not multiples of 4: unfused passes
     ent = L.dpc_conv_gn_entries(H, W)
     assert ent == (H // 8) * (W // 8)
     part = torch.full((n * ent * Co * 2,), float("nan"), device=dev)

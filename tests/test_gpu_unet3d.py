@@ -350,7 +350,23 @@ def test_residual_stream_outside_the_f16x3_range_fails_at_the_end_of_sample(dev)
     bad["init_conv.bias"] = torch.full_like(bad["init_conv.bias"], 6000.0)
     with pytest.raises(RuntimeError, match="left the range the f16x3 arithmetic represents"):
         sampler(bad).sample(**kw)
-    assert torch.isfinite(sampler(bad, arithmetic="x6").sample(**kw)).all()      # the exact mode has no such range
+    exact = sampler(bad, arithmetic="x6")
+    want = exact.sample(**kw)
+    assert torch.isfinite(want).all()                                            # the exact mode has no such range
+    # opt-in (r06): the same call degrades to slow-and-right instead of raising -- the chain is re-run in x6 on the SAME noise epoch,
+    # so the result is bit-identical to a sampler that was exact from the start, and the denoisers stay exact afterwards
+    import warnings
+    gd = sampler(bad)
+    gd.retry_exact = True
+    gd.noise_epoch = exact.noise_epoch = 0
+    want = exact.sample(**kw)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = gd.sample(**kw)
+    assert any("exact x6 arithmetic" in str(x.message) for x in w) and gd.exact_retries == 1
+    assert torch.equal(got, want)
+    assert gd.model_joint.arithmetic == gd.model_thetas.arithmetic == "x6" and "conv=x6" in gd.model_joint.modes
+    assert torch.equal(gd.sample(**kw), want) and gd.exact_retries == 1          # no second retry: already exact
 
 
 def test_unet3d_full_width_32_frames_vs_oracle(dev):

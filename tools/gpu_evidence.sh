@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): parity tests, the full bench line, rocprofv3 kernel stats and the PMC passes, summarised there.
 #   gpurun --timeout 2400 -- 'bash tools/gpu_evidence.sh r02_b'
 # Leaves under gpurun_out/<tag>/ only what gets committed to profiles/: gpu_tests.log, bench.json, kernel_stats.csv,
-# pmc_traffic.json, pmc_sq.json.
+# pmc_traffic.json, pmc_sq.json (the last two also as profiles/pmc_traffic.json / profiles/pmc_sq.json: what bench.py's roofline reads).
 TAG=${1:-run}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT

@@ -101,7 +101,8 @@ def sq_summary(path, dst):
         cyc = v["GRBM_GUI_ACTIVE"] / 8.0
         out[cls] = {"launches": n[cls], "avg_us": dur[cls] / n[cls] / 1e3,
                     "shader_clock_ghz": cyc / max(dur[cls], 1),
-                    "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4) if cyc else 0.0}
+                    "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4) if cyc else 0.0,
+                    "kernel_source_sha16": source_stamp(cls)}
         print(f"{cls:28s} launches {n[cls]:6d} avg {out[cls]['avg_us']:9.1f} us  clock {out[cls]['shader_clock_ghz']:.2f} GHz"
               f"  MFMA busy {100 * out[cls]['mfma_busy_frac']:5.1f} %")
     out["_note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; mfma_busy_frac = MFMA busy cycles / "
