@@ -47,6 +47,13 @@
 // Perf attribution (DPC_ENABLE_CONV_DBG builds, env DPC_CONV_DBG; results INVALID): 2 the loader skips its global loads, 32 the
 // loader does nothing but the barriers, 8 no epilogue, 4 every MFMA wave streams component 0's weights for both of its streams,
 // 16 weight fragments are loaded once (three taps' worth, then re-used), 64 activation fragments are read from LDS during the first chunk only.
+// Compile-time attribution (tools/conv_stamps_w4.py with -DDPC_CONV_STAMPS; no branch enters the instruction stream, unlike the bits):
+// -DDPC_W4_ATTR_NOW no weight loads after the first three taps, _NOA no activation-fragment LDS reads after the first chunk, _NOL the loader
+// requests its halo but does not process it, _NOH the loader requests nothing.  Measured (profiles/r06_l_stamps_attr.log, 256 -> 256 at
+// 16 x 16, shader cycles per chunk of the MFMA waves' tap phase; 5184 = back-to-back MFMA issue): product 7765, NOW 6079, NOA 7356,
+// NOL 7584, NOH 6740, NOW+NOL 5625, NOW+NOA+NOL 5376.  I.e. the tap phase runs at 1.50 x its issue time and the excess is the CU's
+// vector-memory path: the MFMA waves' own weight requests cost them 1.7 k cycles per chunk and the loader waves' 42 halo requests another
+// 1.0 k; the loader's arithmetic costs 0.2 k, the LDS fragment reads 0.4 k.
 // Reference op: nn.Conv3d(dim, dim_out, (3,3,3), padding=(1,1,1)) in Block (video_diffusion_pytorch_conv3d.py:189-204).
 #include "common.h"
 #include "f3c.h"
@@ -189,7 +196,12 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
             rs.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32) & 0xffff);
             rs.z = __builtin_amdgcn_readfirstlane((int)(s1 ? nrec1 : nrec0));
             rs.w = 0x00020000;
+#ifdef DPC_W4_ATTR_NOH          // attribution builds: no halo loads (compile-time form of bit 2)
+            const bool cok = false;
+            if (true) return;
+#else
             const bool cok = c0 + hslot < K && !(CONV_DBG_BUILD && (p.dbg & 2));
+#endif
             const int fbytes = fstride * cs * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -295,6 +307,9 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
         };
         auto finish = [&](int kc, unsigned fok, int in0, int in1, f32x4 (&d)[2][HFI], const f32x4 (&cf)[2], int boff) {
             if (CONV_DBG_BUILD && (p.dbg & 32)) return;
+#ifdef DPC_W4_ATTR_NOL
+            return;
+#endif
             const bool cok = kc * KC + hslot < K;
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             const f32x4 A = (GN && cok) ? cf[0] : zero, B = (GN && cok) ? cf[1] : zero;
@@ -491,6 +506,9 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
     };
     bool dbg_w_once = false;                              // attribution bit 16: weight fragments are loaded for the first two taps only
     auto ldw = [&](f16x8 (&da)[2][2], f16x8 (&db)[2]) {
+#ifdef DPC_W4_ATTR_NOW          // compile-time form of bit 16 (no branch in the stream): tools/conv_stamps_w4.py attribution builds
+        if (dbg_w_once) return;
+#endif
         if (CONV_DBG_BUILD && (p.dbg & 16) && dbg_w_once) return;
         const unsigned char* src = wnext + wlo;
         if (++wtap_i == NTAPS) {
@@ -515,11 +533,18 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
         ldw(wA[2], wB[2]);
         dbg_w_once = true;
     }
+#ifdef DPC_W4_ATTR_NOW
+    ldw(wA[2], wB[2]);
+    dbg_w_once = true;
+#endif
 
     int boff = 0;
     // fragments of slab q (plane rows 4 q .. 4 q + 3) of a component's transformed frame for tap (dh, dw): both planes
     bool dbg_a_once = false;                              // attribution bit 64: activation fragments are read from LDS once per launch
     auto lda = [&](f16x8 (&dst)[2], int addr, int q) {
+#ifdef DPC_W4_ATTR_NOA
+        if (dbg_a_once) return;
+#endif
         if (CONV_DBG_BUILD && (p.dbg & 64) && dbg_a_once) return;
         dst[0] = *reinterpret_cast<const f16x8*>(halo + addr + q * 2560);
         dst[1] = *reinterpret_cast<const f16x8*>(halo + (addr ^ 32) + q * 2560);
@@ -600,6 +625,9 @@ __global__ __launch_bounds__(512, 2) void conv3w4_kernel(Conv3hParams p) {
             for (int tap = 0; tap < NTAPS; ++tap) tap_body(tap);
             lap(0);
             if (CONV_DBG_BUILD && (p.dbg & 64)) dbg_a_once = true;
+#ifdef DPC_W4_ATTR_NOA
+            dbg_a_once = true;
+#endif
             // MFMA B-operand guard (third hazard): the next chunk's first fragment loads may be given the registers of the
             // fragments the last MFMAs read (hipcc re-uses them: tools/mfma_war_audit.py) -- the wave waits for the last MFMA of both
             // component-B chains (the youngest six MFMAs of the chunk) before it enters the barrier
