@@ -663,7 +663,8 @@ def run_s128_leg(ctx, args, t_start, batch=64):
     """BASELINE.json configs[4] (S128: 128 x 128 x 64 frames, prior-reweighted dual diffusion, batch 512 over 8 GPUs = 64 per GPU),
     micro-batch 8: the headline step at that extent and at the config's per-GPU batch (r04 ran B = 8)."""
     from diffphycon_amd.diffusion.diffusion_2d_smoke import SmokeGuidance
-    gd, _ = build_models(ctx.device, 8, frames=64, size=128)      # micro-batch 8 (B = 8, r03: 1: 361 ms per step, 2: 326, 4: 308; B = 16, r05: 4: 616.6, 8: 609.5)
+    mb = int(os.environ.get("DPC_S128_MICRO_BATCH", "8"))
+    gd, _ = build_models(ctx.device, mb, frames=64, size=128)     # micro-batch 8 (B = 8, r03: 1: 361 ms per step, 2: 326, 4: 308; B = 16, r05: 4: 616.6, 8: 609.5)
     guide = SmokeGuidance((2.0, 18.0, 20.0, 16.0, 20.0, 1.0), 0.0)
     gd.noise_seed, gd.traj_offset = 0, ctx.rank * batch
     init = torch.nn.functional.interpolate(synthetic_init(batch, ctx.rank * batch)[:, None], scale_factor=2)[:, 0].to(ctx.device)
@@ -681,7 +682,7 @@ def run_s128_leg(ctx, args, t_start, batch=64):
             "unit": "trajectories/s", "n_gpus": ctx.world, "steps": args.steps, "ms_per_step": sec * 1e3,
             "ms_per_step_min_rank": sec_min * 1e3, "world_size_seen_by_rccl": ctx.seen_world, "dtype": dtype_label(gd.model_joint.modes),
             "roofline_step": step_roofline(gd.model_joint.modes, batch * 14534.0e9, sec, f"{batch} x 14534 GFLOP (SURVEY.md 8d) per step / ms_per_step"),
-            "config": {"workload": f"S128 (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU (512 / 8), micro-batch 8",
+            "config": {"workload": f"S128 (BASELINE.json configs[4]): 2D smoke 128x128 x 64 frames, batch={batch} per GPU (512 / 8), micro-batch {mb}",
                        "global_batch": ctx.world * batch, "parallelism": f"batch-shard x{ctx.world}"},
             "roofline": None, "roofline_null_reason": "per-class events are taken on the S64 headline only; roofline_step covers this leg",
             "cpu_baseline": None,

@@ -99,7 +99,7 @@ def test_conv3d_winograd_small_and_large_inputs(scale, dev, L):
     65504 for |d| <= 4094, the range every f16x3 kernel guarantees), where the direct kernels use 2^4: for a tensor whose values are
     ALL of magnitude ~1e-3 the remainder plane sits in fp16's subnormals and carries 4-5 bits.  The 3e-6-of-range bound of the
     other cases holds from |x| ~ 1e-2 upwards; at 1e-3 the error stays inside SURVEY 8d's per-block 1e-5 (measured 9.5e-6 with
-    F(4,3), 1.3e-6 with F(2,3) and its pre-scale of 8).  Magnitude 100 checks the other end of the window."""
+    F(4,3); F(2,3) with its pre-scale of 8 stayed below 3e-6 there).  Magnitude 100 checks the other end of the window."""
     B, Fr, H, W, Ci, Co = 1, 8, 16, 16, 64, 64
     g = torch.Generator().manual_seed(int(scale * 1000) + 5)
     x = torch.randn(B, Ci, Fr, H, W, generator=g) * scale
