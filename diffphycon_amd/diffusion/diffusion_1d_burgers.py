@@ -206,6 +206,9 @@ class GaussianDiffusion(nn.Module):
         self.noise_epoch, self._calls = None, 0      # see diffusion_2d_smoke._begin_noise_epoch
         self._draw = 0
         self.use_graph = os.environ.get("DPC_BURGERS_GRAPH", "1") != "0"     # HIP-graph replay of the denoiser forwards
+        # r06: the prior net on a forked side stream (two parallel branches of the captured graph): 16.65 -> 15.02 ms per POPC step at
+        # B = 256, bit-identical (tests/test_gpu_burgers_sampler.py); DPC_BURGERS_TWO_STREAMS=0 restores the single stream
+        self.two_streams = os.environ.get("DPC_BURGERS_TWO_STREAMS", "1") != "0"
         self._graphs, self._t_static = {}, None
 
     # ------------------------------------------------------------------ noise
@@ -260,8 +263,26 @@ class GaussianDiffusion(nn.Module):
 
     def _denoise(self, img, x_w, t_b):
         if self.eval_two_models:
+            if getattr(self, "two_streams", False):
+                # the two denoisers are independent (own weights, own workspaces): the prior net runs on a side stream, forked from and
+                # joined to the current one -- inside a HIP-graph capture this becomes two parallel branches of the graph.  At B = 256 most
+                # launches of these nets do not fill the device (deep levels: 64 workgroups), so the branches overlap.
+                cur = torch.cuda.current_stream()
+                side = self._side_stream()
+                side.wait_stream(cur)
+                e_uw = self.model_uw(img, t_b)
+                with torch.cuda.stream(side):
+                    e_w = self.model_w(x_w, t_b)
+                cur.wait_stream(side)
+                return e_uw, e_w
             return self.model_uw(img, t_b), self.model_w(x_w, t_b)
         return self.model(img, t_b), None
+
+    def _side_stream(self):
+        s = getattr(self, "_side", None)
+        if s is None:
+            s = self._side = torch.cuda.Stream()
+        return s
 
     def _denoise_step(self, img, x_w, t: int):
         """The two denoiser forwards of step t.  With `use_graph` the several hundred launches of the two Unet2D forwards are

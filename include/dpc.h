@@ -65,9 +65,11 @@ const char* dpc_last_error(void);
 int dpc_set_mode(const char* family, const char* mode);
 const char* dpc_get_mode(const char* family);
 /* Which algorithm the f16x3 3x3x3 convolution (Block.proj, video_diffusion_pytorch_conv3d.py:189-204) runs for the shapes that
- * qualify: "winograd_f23_frames" (default: minimal filtering F(2,3) along the frame axis, 2/3 of the matrix products of the
- * direct form, same 22-bit split operands and fp32 accumulation; csrc/conv3w.hip) or "direct" (DPC_CONV3W=0).  Reported next
- * to the arithmetic modes by bench.py: roofline.achieved counts ALGORITHMIC (direct-form) FLOP in both cases. */
+ * qualify: "winograd_f43_frames" (default since r06: minimal filtering F(4,3) along the frame axis, interpolation points (0, 1, -1, 1/2,
+ * -2, inf), 1/2 of the matrix products of the direct form, same 22-bit split operands and fp32 accumulation; csrc/conv3w4.hip),
+ * "winograd_f23_frames" (F(2,3), 2/3 of the products; csrc/conv3w.hip; DPC_DEBUG=1 DPC_CONV3W_F43=0) or "direct" (DPC_CONV3W=0).
+ * Reported next to the arithmetic modes by bench.py: roofline.achieved counts ALGORITHMIC (direct-form) FLOP in all cases,
+ * roofline.mfma_issue_frac the issued ones. */
 const char* dpc_conv3d_algorithm(void);
 
 /* Opt-in timing of every kernel launch with HIP events on the launch stream, aggregated per kernel class

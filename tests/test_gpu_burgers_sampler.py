@@ -209,6 +209,41 @@ def test_graph_replay_follows_weight_reloads(g, dev):
     assert not torch.equal(outs[True][0], outs[True][1])          # the reload changed the result
 
 
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_two_stream_denoisers_equal_the_single_stream_run(g, use_graph, dev):
+    """r06: the prior denoiser runs on a forked side stream (inside the captured HIP graph: a parallel branch).  Same kernels, same
+    inputs, own workspaces and per-stream scratch: the sampled batch must be bit-identical to the single-stream schedule -- on the tiny
+    fixture nets and at the POPC width (dim 64, mults (1,2,4,8,16) / (1,2,4,8)), whose deep levels are the launches that overlap."""
+    c = CASES["popc"]
+    outs = {}
+    for two in (False, True):
+        gd, kwargs, _ = build(g, c, dev)
+        gd.use_graph, gd.two_streams = use_graph, two
+        gd.noise_seed, gd.guidance_batch, gd.noise_epoch = 5, 3, 0
+        outs[two] = gd.sample(batch_size=3, **kwargs)
+    assert torch.equal(outs[False], outs[True])
+    # full width, a few steps of the chain, several repetitions (a race would not show every time)
+    from diffphycon_amd.model.burgers_1d.unet import Unet2D
+    from diffphycon_amd.diffusion import diffusion_1d_burgers as D
+    torch.manual_seed(0)
+    kw = dict(dim=64, out_dim=2, channels=2, resnet_block_groups=1)
+    nets = (Unet2D(dim_mults=(1, 2, 4, 8, 16), **kw).to(dev), Unet2D(dim_mults=(1, 2, 4, 8), **kw).to(dev))
+    B = 32
+    x = torch.randn(B, 2, 16, 128, device=dev)
+    xw = x.clone()
+    ref = None
+    for two in (False, True, True, True):
+        gd = D.GaussianDiffusion(nets, seq_length=(16, 128), timesteps=1000, auto_normalize=False, use_conv2d=True, temporal=True,
+                                 eval_two_models=True, prior_beta=0.9, normalize_beta=False).to(dev)
+        gd.use_graph, gd.two_streams = use_graph, two
+        got = [t.clone() for step in (999, 500, 3) for t in gd._denoise_step(x, xw, step)]
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), two
+
+
 def test_recurrent_sample_matches_reference(dev):
     """--recurrence (diffusion_1d_burgers.py:472-482): the re-noising step against the reference's teacher-forced records, and the
     loop structure (:535-582): recurrence_k passes per diffusion step, each followed by the re-noising."""
