@@ -86,8 +86,8 @@ struct ModeScope {
 };
 // Opt-in activation range check of the f16x3 mode (dpc_unet*_set_range_check).  Range contract per kernel family: every f16x3
 // kernel represents |x| <= 4094 with 22 significant bits; beyond it the direct convolutions / implicit GEMMs / stem (conv3f3.hip /
-// igemm6.hip / stem7x6.hip: pre-scale SA = 16) CLAMP at 65504 / 2^4 = 4094, while the Winograd convolution (conv3w.hip: no
-// pre-scale; since r03 2^3 inside the operand split) stays exact up to 4094 (plain input) / 5676 (fused GroupNorm input) and then produces inf -> NaN.  With the check on, every f16x3 conv / implicit
+// igemm6.hip / stem7x6.hip: pre-scale SA = 16) CLAMP at 65504 / 2^4 = 4094, while the Winograd convolutions (conv3w4.hip, F(4,3):
+// pre-scale 2 / log2 e inside the operand split; conv3w.hip, F(2,3): 2^3 / 4 log2 e) stay exact up to 4678 / 6486 (F(2,3): 4094 / 5676; plain / fused GroupNorm input) and then produce inf -> NaN.  With the check on, every f16x3 conv / implicit
 // GEMM / stem launch of a forward is preceded by a streaming pass over its input (after the fused GroupNorm+SiLU where the
 // halo staging applies one) that records the first op whose input leaves the range; the forward then FAILS instead of
 // returning a result computed from clamped activations.  Off by default (costs one extra read of every conv input).
@@ -315,7 +315,8 @@ struct Conv3hParams {
     const float* a1;        // virtual concat source [B,F,H,W,C1] or null
     int C0, C1;
     const float* wp;        // [27][kchunks][Npad][16]
-    const void* wpw;        // f16x3 only: Winograd-transformed pack [4][9][kchunks][Npad][2][16] fp16 (conv3w.hip) or null
+    const void* wpw;        // f16x3 only: Winograd-transformed pack -- F(4,3), default: [6][9][kchunks][Npad/32][2][2][32][8] fp16 (conv3w4.hip);
+                            // F(2,3): [4][9][kchunks][Npad][2][16] (conv3w.hip); launch_pack_weights_w3 writes the form launch_conv3w runs -- or null
     const float* bias;
     float* out;             // channels-last [B,F,H,W,N]
     int B, F, H, W;

@@ -29,7 +29,7 @@ struct PackedConv {
     bool halo = false;      // 3x3x3 stride-1 conv: packed with bk = 16 for the LDS halo-tile kernel (conv3h.hip)
     DevBuf wp6;             // ... and pre-split into 3 bf16 planes for the bf16x6 kernel (conv3x6.hip)
     DevBuf wp3;             // ... or into 2 fp16 planes for the f16x3 kernel (conv3f3.hip)
-    DevBuf wpw;             // f16x3 3x3x3 convs: the Winograd F(2,3)-over-frames pack as well (conv3w.hip)
+    DevBuf wpw;             // f16x3 3x3x3 convs: the Winograd-over-frames pack as well (F(4,3): conv3w4.hip; F(2,3): conv3w.hip)
     DevBuf wp6g;            // every other op: pre-split planes for the bf16x6 implicit GEMM (igemm6.hip)
     signed char tdf[32], tdh[32], tdw[32];
 };
