@@ -93,6 +93,46 @@ def test_conv3d_cl(case, dev, L):
     assert relerr(got, ref) < 3e-6, relerr(got, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64, 64), (1, 32, 32, 32, 256, 128), (1, 64, 32, 32, 128, 128), (2, 20, 32, 32, 64, 128)])
+def test_conv3d_winograd_at_full_layer_extents_sampled_vs_fp64(shape, dev, L):
+    """The Winograd F(4,3) kernel at the REAL extents of the BASELINE configs' layers (S64 level 0: 32 x 64 x 64, 64 -> 64; a concatenated
+    up-path layer 256 -> 128; S128's 64 frames; J128's 20 frames) -- too large for a full fp64 reference in the GPU suite, so the launch
+    is full-size and the check is exact fp64 dot products at sampled output positions: 2048 random ones and every combination of the
+    tile seams (frames 0, 3, 4, F-1; rows / columns 0, 7, 8, last) for three output channels.  Same 3e-6-of-range bound as the small
+    cases (the persistent tile walk, the XCD-aware tile order and the deferred stores only show at sizes with many tiles per CU)."""
+    B, Fr, H, W, Ci, Co = shape
+    g = torch.Generator(device=dev).manual_seed(Ci + Co + Fr)
+    x = torch.randn(B, Fr, H, W, Ci, device=dev, generator=g)                 # channels-last
+    w = torch.randn(Co, Ci, 3, 3, 3, device=dev, generator=g) / (Ci * 27) ** 0.5
+    b = torch.randn(Co, device=dev, generator=g)
+    out = torch.empty(B, Fr, H, W, Co, device=dev)
+    ws = L.workspace(L.lib().dpc_conv_workspace_bytes(Ci, Co, 27), dev)
+    L.check(L.lib().dpc_conv3d_cl(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), B, Fr, H, W, Ci, Co, 3, 3, 3, 1, 1, 1, 1, 1, 1,
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), L.stream()))
+    rng = np.random.RandomState(Ci * 7 + Fr)
+    pts = [(rng.randint(B), rng.randint(Fr), rng.randint(H), rng.randint(W), rng.randint(Co)) for _ in range(2048)]
+    for f in sorted({0, 3, 4, Fr - 1}):
+        for h in sorted({0, 7, 8, H - 1}):
+            for ww in sorted({0, 7, 8, W - 1}):
+                for n in (0, Co // 2 + 1, Co - 1):
+                    pts.append((B - 1, f, h, ww, n))
+    idx = torch.tensor(pts, device=dev)
+    xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1, 1, 1))          # zero halo on f, h, w
+    bi, fi, hi, wi, ni = idx.unbind(1)
+    ref = b.double()[ni].clone()
+    wd = w.double()
+    for df in range(3):
+        for dh in range(3):
+            for dw in range(3):
+                ref += (xp[bi, fi + df, hi + dh, wi + dw] * wd[ni, :, df, dh, dw]).sum(1)
+    got = out[bi, fi, hi, wi, ni].double()
+    scale = out.abs().max().double()
+    err = ((got - ref).abs().max() / scale).item()
+    print(f"conv3w4 {shape}: sampled error {err:.3e} of the output range at {len(pts)} points")
+    assert err < 3e-6, (shape, err)
+    assert torch.isfinite(out).all()
+
+
 @pytest.mark.parametrize("scale", [1e-3, 1e-2, 3e-2, 100.0])
 def test_conv3d_winograd_small_and_large_inputs(scale, dev, L):
     """The Winograd kernel splits a plain (un-normalised) input with a pre-scale of 2 only (F(4,3): |B^T d| <= 7 |d| must stay below
